@@ -1,0 +1,427 @@
+// C ABI of libcompu_hip.so (include/compu_hip.h): device/buffer management, the batched entry
+// points, and the streaming Decoder/Encoder objects that mirror compu's vtables
+// (src/decoder/mod.rs:160-166, src/encoder/mod.rs:52-57) on top of the batched GPU kernels.
+//
+// The streaming objects keep compu's call contract (NeedInput / NeedOutput / Finished, borrowed
+// host buffers) but do all codec work on the GPU: input is accumulated in pinned host memory,
+// the whole stream seen so far is decoded by the batch kernel (a batch of one), and decoded bytes
+// are handed out of a device buffer as the caller provides room -- the same shape as brotli's
+// internally buffered decoder that tests/decoder.rs:38-39 already allows for.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+
+#include "chip_internal.h"
+
+using namespace chip;
+
+namespace {
+
+chip_malloc_fn g_malloc = nullptr;
+chip_free_fn g_free = nullptr;
+void *g_opaque = nullptr;
+
+void *host_alloc(size_t n) { return g_malloc ? g_malloc(g_opaque, n) : malloc(n); }
+void host_free(void *p)
+{
+    if (!p) return;
+    if (g_free) g_free(g_opaque, p);
+    else free(p);
+}
+
+bool device_ok()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+// small device+pinned block holding the per-unit descriptor and result words of a batch of one
+struct Meta {
+    uint64_t in_off, out_off;
+    uint32_t in_len, out_cap, out_len, in_used;
+    int32_t status;
+    uint32_t pad;
+};
+
+}  // namespace
+
+extern "C" {
+
+int chip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int chip_set_device(int device) { return hipSetDevice(device) == hipSuccess ? CHIP_OK : CHIP_E_NO_DEVICE; }
+
+const char *chip_version(void) { return "compu-hip 0.1 (gfx950)"; }
+
+void chip_set_allocator(chip_malloc_fn malloc_fn, chip_free_fn free_fn, void *opaque)
+{
+    g_malloc = malloc_fn;
+    g_free = free_fn;
+    g_opaque = opaque;
+}
+
+void *chip_device_alloc(size_t size)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, size ? size : 4) != hipSuccess) return nullptr;
+    return p;
+}
+void chip_device_free(void *ptr)
+{
+    if (ptr) (void)hipFree(ptr);
+}
+void *chip_pinned_alloc(size_t size)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, size ? size : 4, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+void chip_pinned_free(void *ptr)
+{
+    if (ptr) (void)hipHostFree(ptr);
+}
+int chip_memcpy_h2d(void *dst, const void *src, size_t size, void *stream)
+{
+    return hipMemcpyAsync(dst, src, size, hipMemcpyHostToDevice, (hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
+}
+int chip_memcpy_d2h(void *dst, const void *src, size_t size, void *stream)
+{
+    return hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
+}
+int chip_stream_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH; }
+
+// ---- batched decode ------------------------------------------------------------------------
+
+int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                      void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                      uint32_t *in_used, int32_t *status, void *stream)
+{
+    if (n == 0) return CHIP_OK;
+    if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !in_used ||
+        !status || ((uintptr_t)in_base & 3u))
+        return CHIP_E_INVALID;
+    if (!device_ok()) return CHIP_E_NO_DEVICE;
+    BatchArgs a;
+    a.in_base = (const uint8_t *)in_base;
+    a.in_off = in_off;
+    a.in_len = in_len;
+    a.out_base = (uint8_t *)out_base;
+    a.out_off = out_off;
+    a.out_cap = out_cap;
+    a.out_len = out_len;
+    a.in_used = in_used;
+    a.status = status;
+    a.n = (uint32_t)n;
+    a.format = format;
+    hipError_t e;
+    switch (format) {
+    case CHIP_FMT_DEFLATE:
+    case CHIP_FMT_ZLIB:
+    case CHIP_FMT_GZIP:
+    case CHIP_FMT_AUTO: e = launch_inflate(a, (hipStream_t)stream); break;
+    case CHIP_FMT_ZSTD: e = launch_zstd_decode(a, 0, (hipStream_t)stream); break;
+    default: return CHIP_E_INVALID;
+    }
+    return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
+}
+
+// Detection::detect, src/decoder/mod.rs:28-114 (including the fall-through of the 0x68 arm,
+// src/decoder/mod.rs:80-82, which makes `68 xx` zlib headers come out as Unknown).
+int chip_detect(const uint8_t *b, size_t len)
+{
+    if (len < 2) return CHIP_DETECT_NONE;
+    if (b[0] == 0x1f && b[1] == 0x8b) return CHIP_DETECT_GZIP;
+    if ((((unsigned)b[0] << 8) | b[1]) % 31 == 0) {
+        static const uint8_t flg[8][4] = {{0x1d, 0x5b, 0x99, 0xd7}, {0x19, 0x57, 0x95, 0xd3}, {0x15, 0x53, 0x91, 0xcf},
+                                          {0x11, 0x4f, 0x8d, 0xcb}, {0x0d, 0x4b, 0x89, 0xc7}, {0x09, 0x47, 0x85, 0xc3},
+                                          {0x05, 0x43, 0x81, 0xde}, {0x01, 0x5e, 0x9c, 0xda}};
+        if ((b[0] & 0x8f) == 0x08 && b[0] != 0x68) {
+            const uint8_t *row = flg[b[0] >> 4];
+            for (int i = 0; i < 4; i++)
+                if (b[1] == row[i]) return CHIP_DETECT_ZLIB;
+        }
+    }
+    if (len < 4) return CHIP_DETECT_NONE;
+    if (b[0] == 0x28 && b[1] == 0xb5 && b[2] == 0x2f && b[3] == 0xfd) return CHIP_DETECT_ZSTD;
+    return CHIP_DETECT_UNKNOWN;
+}
+
+int chip_detect_batch(size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
+                      void *stream)
+{
+    if (n == 0) return CHIP_OK;
+    if (!in_base || !in_off || !in_len || !kind) return CHIP_E_INVALID;
+    if (!device_ok()) return CHIP_E_NO_DEVICE;
+    return launch_detect(n, (const uint8_t *)in_base, in_off, in_len, kind, (hipStream_t)stream) == hipSuccess ? CHIP_OK
+                                                                                                               : CHIP_E_LAUNCH;
+}
+
+// ---- error strings -------------------------------------------------------------------------
+
+const char *chip_decoder_strerror(int format, int32_t code)
+{
+    if (format == CHIP_FMT_ZSTD) {
+        // ZSTD_getErrorName(code as usize), src/decoder/zstd.rs:159-164
+        switch (code < 0 ? -code : code) {
+        case 0: return "No error detected";
+        case 1: return "Error (generic)";
+        case 10: return "Unknown frame descriptor";
+        case 12: return "Version not supported";
+        case 14: return "Unsupported frame parameter";
+        case 16: return "Frame requires too much memory for decoding";
+        case 20: return "Data corruption detected";
+        case 22: return "Restored data doesn't match checksum";
+        case 30: return "Dictionary is corrupted";
+        case 32: return "Dictionary mismatch";
+        case 64: return "Allocation error : not enough memory";
+        case 70: return "Destination buffer is too small";
+        case 72: return "Src size is incorrect";
+        default: return "Unspecified error code";
+        }
+    }
+    // zError, src/decoder/zlib_ng.rs:118-123
+    static const char *const tab[] = {"need dictionary", "stream end", "", "file error", "stream error",
+                                      "data error", "insufficient memory", "buffer error", "incompatible version", ""};
+    int idx = 2 - code;
+    if (idx < 0 || idx > 9) idx = 9;
+    return tab[idx];
+}
+
+}  // extern "C"
+
+// ---- streaming decoder -----------------------------------------------------------------------
+
+struct chip_decoder {
+    int format;
+    int device;
+    int window_log_max;
+    hipStream_t stream;
+    uint8_t *h_in;   // pinned: every input byte of the current stream
+    size_t h_in_cap, h_in_len;
+    uint8_t *d_in;
+    size_t d_in_cap;
+    uint8_t *d_out;
+    size_t d_out_cap;
+    Meta *d_meta;
+    Meta *h_meta;    // pinned
+    bool decoded;    // kernel results below describe h_in[0..h_in_len)
+    uint32_t k_out_len, k_in_used;
+    int32_t k_status;
+    size_t delivered;  // decoded bytes already handed to the caller
+    bool done;
+};
+
+namespace {
+
+bool dec_reserve_in(chip_decoder *d, size_t need)
+{
+    if (need <= d->h_in_cap) return true;
+    size_t cap = d->h_in_cap ? d->h_in_cap : 65536;
+    while (cap < need) cap *= 2;
+    uint8_t *p = (uint8_t *)chip_pinned_alloc(cap);
+    if (!p) return false;
+    if (d->h_in_len) memcpy(p, d->h_in, d->h_in_len);
+    chip_pinned_free(d->h_in);
+    d->h_in = p;
+    d->h_in_cap = cap;
+    return true;
+}
+
+// decode everything accumulated so far; grows the device output until it is not the limit
+bool dec_run(chip_decoder *d)
+{
+    if (hipSetDevice(d->device) != hipSuccess) return false;
+    size_t in_len = d->h_in_len;
+    size_t need_in = (in_len + 3) & ~(size_t)3;
+    if (need_in + 16 > d->d_in_cap) {
+        chip_device_free(d->d_in);
+        d->d_in_cap = need_in * 2 + 4096;
+        d->d_in = (uint8_t *)chip_device_alloc(d->d_in_cap);
+        if (!d->d_in) return false;
+    }
+    if (in_len && hipMemcpyAsync(d->d_in, d->h_in, in_len, hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
+    size_t cap = d->d_out_cap;
+    if (cap == 0) cap = in_len * 4 > 65536 ? in_len * 4 : 65536;
+    for (;;) {
+        if (cap > 0xffffffffull) cap = 0xffffffffull;
+        if (cap > d->d_out_cap) {
+            chip_device_free(d->d_out);
+            d->d_out = (uint8_t *)chip_device_alloc(cap);
+            if (!d->d_out) {
+                d->d_out_cap = 0;
+                return false;
+            }
+            d->d_out_cap = cap;
+        }
+        Meta m = {0, 0, (uint32_t)in_len, (uint32_t)d->d_out_cap, 0, 0, 0, 0};
+        *d->h_meta = m;
+        if (hipMemcpyAsync(d->d_meta, d->h_meta, sizeof(Meta), hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
+        BatchArgs a;
+        a.in_base = d->d_in;
+        a.in_off = &d->d_meta->in_off;
+        a.in_len = &d->d_meta->in_len;
+        a.out_base = d->d_out;
+        a.out_off = &d->d_meta->out_off;
+        a.out_cap = &d->d_meta->out_cap;
+        a.out_len = &d->d_meta->out_len;
+        a.in_used = &d->d_meta->in_used;
+        a.status = &d->d_meta->status;
+        a.n = 1;
+        a.format = d->format;
+        hipError_t e = d->format == CHIP_FMT_ZSTD ? launch_zstd_decode(a, d->window_log_max, d->stream) : launch_inflate(a, d->stream);
+        if (e != hipSuccess) return false;
+        if (hipMemcpyAsync(d->h_meta, d->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;
+        if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
+        if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < 0xffffffffull) {
+            cap = d->d_out_cap * 2;
+            continue;
+        }
+        break;
+    }
+    d->k_out_len = d->h_meta->out_len;
+    d->k_in_used = d->h_meta->in_used;
+    d->k_status = d->h_meta->status;
+    d->decoded = true;
+    return true;
+}
+
+void dec_clear(chip_decoder *d)
+{
+    d->h_in_len = 0;
+    d->decoded = false;
+    d->k_out_len = d->k_in_used = 0;
+    d->k_status = CHIP_NEED_INPUT;
+    d->delivered = 0;
+    d->done = false;
+}
+
+}  // namespace
+
+extern "C" {
+
+chip_decoder *chip_decoder_new(int format, const chip_decoder_opts *opts)
+{
+    if (format != CHIP_FMT_DEFLATE && format != CHIP_FMT_ZLIB && format != CHIP_FMT_GZIP && format != CHIP_FMT_AUTO &&
+        format != CHIP_FMT_ZSTD)
+        return nullptr;
+    if (!device_ok()) return nullptr;  // no CPU codec behind this backend
+    int device = opts ? opts->device : -1;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    chip_decoder *d = (chip_decoder *)host_alloc(sizeof(chip_decoder));
+    if (!d) return nullptr;
+    memset(d, 0, sizeof *d);
+    d->format = format;
+    d->device = device;
+    d->window_log_max = opts ? opts->window_log_max : 0;
+    if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+        host_free(d);
+        return nullptr;
+    }
+    d->d_meta = (Meta *)chip_device_alloc(sizeof(Meta));
+    d->h_meta = (Meta *)chip_pinned_alloc(sizeof(Meta));
+    if (!d->d_meta || !d->h_meta || !dec_reserve_in(d, 65536)) {
+        chip_decoder_free(d);
+        return nullptr;
+    }
+    dec_clear(d);
+    return d;
+}
+
+chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len)
+{
+    chip_decode_result r = {in_len, out_len, CHIP_NEED_INPUT, 0};
+    if (!d) {
+        r.status = -1;
+        r.err = -2;  // Z_STREAM_ERROR
+        return r;
+    }
+    if (d->done) {
+        // like zlib in its DONE state: Finished again, nothing consumed
+        r.status = CHIP_FINISHED;
+        return r;
+    }
+    const bool stream_end_known = d->decoded && (d->k_status == CHIP_FINISHED || d->k_status < 0 || d->k_status == Z_NEED_DICT);
+    size_t taken = 0;
+    if (!stream_end_known && in_len) {
+        if (!dec_reserve_in(d, d->h_in_len + in_len)) {
+            r.status = -1;
+            r.err = -4;  // Z_MEM_ERROR
+            return r;
+        }
+        memcpy(d->h_in + d->h_in_len, in, in_len);
+        d->h_in_len += in_len;
+        taken = in_len;
+        d->decoded = false;
+    }
+    if (!d->decoded && !dec_run(d)) {
+        r.status = -1;
+        r.err = -4;
+        return r;
+    }
+    size_t avail = d->k_out_len - d->delivered;
+    size_t n = avail < out_len ? avail : out_len;
+    if (n) {
+        (void)hipSetDevice(d->device);
+        if (hipMemcpyAsync(out, d->d_out + d->delivered, n, hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+            hipStreamSynchronize(d->stream) != hipSuccess) {
+            r.status = -1;
+            r.err = -4;
+            return r;
+        }
+        d->delivered += n;
+    }
+    r.output_remain = out_len - n;
+    // bytes of this call that lie behind the end of the stream go back to the caller
+    size_t giveback = 0;
+    if (d->k_status == CHIP_FINISHED || d->k_status < 0) {
+        size_t trailing = d->h_in_len - d->k_in_used;
+        giveback = trailing < taken ? trailing : taken;
+        d->h_in_len -= giveback;
+    }
+    r.input_remain = (in_len - taken) + giveback;
+    if (d->delivered < d->k_out_len) {
+        r.status = CHIP_NEED_OUTPUT;
+        return r;
+    }
+    if (d->k_status == CHIP_FINISHED) {
+        d->done = true;
+        r.status = CHIP_FINISHED;
+    } else if (d->k_status == CHIP_NEED_INPUT) {
+        // Z_OK with avail_in == 0 -> NeedInput; a call that made no progress at all is zlib's
+        // Z_BUF_ERROR, which compu maps to NeedOutput (src/decoder/mod.rs:476-481)
+        r.status = (in_len == 0 && n == 0) ? CHIP_NEED_OUTPUT : CHIP_NEED_INPUT;
+    } else {
+        r.status = -1;
+        r.err = d->k_status;
+    }
+    return r;
+}
+
+chip_decoder *chip_decoder_reset(chip_decoder *d)
+{
+    if (d) dec_clear(d);
+    return d;
+}
+
+void chip_decoder_free(chip_decoder *d)
+{
+    if (!d) return;
+    (void)hipSetDevice(d->device);
+    if (d->stream) (void)hipStreamDestroy(d->stream);
+    chip_pinned_free(d->h_in);
+    chip_pinned_free(d->h_meta);
+    chip_device_free(d->d_in);
+    chip_device_free(d->d_out);
+    chip_device_free(d->d_meta);
+    host_free(d);
+}
+
+}  // extern "C"

@@ -1,0 +1,9 @@
+#!/bin/bash
+# Builds compu_amd/libcompu_hip.so for gfx950 (cross-compiles without a GPU).
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="$here/../libcompu_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+    -o "$out" "$here"/*.hip "$@"
+echo "built $out"

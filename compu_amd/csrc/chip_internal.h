@@ -1,0 +1,72 @@
+// Internal declarations shared by the HIP translation units of libcompu_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/compu_hip.h"
+
+namespace chip {
+
+// Per-unit running state codes used inside kernels (never exported).
+constexpr int32_t ST_RUNNING = 0x7fffffff;
+
+// zlib return codes carried in DecodeError (src/decoder/mod.rs:482)
+constexpr int32_t Z_NEED_DICT = 2;
+constexpr int32_t Z_DATA_ERROR = -3;
+
+// ZSTD_ErrorCode values carried (negated) in DecodeError (src/decoder/zstd.rs:131)
+constexpr int32_t ZSTD_E_GENERIC = 1;
+constexpr int32_t ZSTD_E_PREFIX_UNKNOWN = 10;
+constexpr int32_t ZSTD_E_FRAMEPARAM_UNSUPPORTED = 14;
+constexpr int32_t ZSTD_E_WINDOW_TOO_LARGE = 16;
+constexpr int32_t ZSTD_E_CORRUPTION = 20;
+constexpr int32_t ZSTD_E_CHECKSUM_WRONG = 22;
+constexpr int32_t ZSTD_E_DICT_WRONG = 32;
+
+struct BatchArgs {
+    const uint8_t *in_base;
+    const uint64_t *in_off;
+    const uint32_t *in_len;
+    uint8_t *out_base;
+    const uint64_t *out_off;
+    const uint32_t *out_cap;
+    uint32_t *out_len;
+    uint32_t *in_used;
+    int32_t *status;
+    uint32_t n;
+    int32_t format;
+};
+
+// launchers (each only enqueues on `stream`)
+hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);
+hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_t stream);
+hipError_t launch_detect(size_t n, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
+                         hipStream_t stream);
+hipError_t launch_deflate_l1(const BatchArgs &a, hipStream_t stream);
+
+// ---- wavefront helpers (wave = 64 lanes, one wave per workgroup in the codec kernels) ----------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+__device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
+}
+__device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const uint32_t l = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
+        if (l >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+// LDS written by some lanes of the (single) wave, read by others: order + visibility
+#define WSYNC() __syncthreads()
+
+}  // namespace chip

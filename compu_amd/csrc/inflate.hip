@@ -1,0 +1,493 @@
+// Batched DEFLATE inflate for gfx950 (MI355X): one wavefront decodes one independent unit.
+//
+// Replaces, per unit, what compu reaches through sys::inflate (src/decoder/mod.rs:470) for a
+// decoder built by Interface::zlib_ng(mode) (src/decoder/zlib_ng.rs:61-90): block-header parse,
+// dynamic-Huffman table build, bitstream decode, LZ77 copy (RFC 1951), and the zlib / gzip
+// wrappers with Adler-32 / CRC-32 verification (RFC 1950 / 1952).
+//
+// Data flow per wave:  compressed bytes --(coalesced dword loads)--> LDS input window
+//   --> canonical-Huffman LUTs in LDS --> token ring in LDS (literal | len,dist)
+//   --> wave prefix sum of token output lengths --> byte scatter of literals and cooperative
+//   LZ77 copies straight into the unit's output range in HBM (the window is the output itself,
+//   L2-resident for a 64 KiB unit).
+#include "chip_internal.h"
+
+namespace chip {
+
+// ---- table entry format (shared by lit/len, distance and code-length tables) -------------------
+// [3:0] code length (0 = longer than the root table, resolve canonically)
+// [7:4] number of extra bits, [9:8] kind, [31:16] base value
+enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_BAD = 3 };
+__device__ __forceinline__ constexpr uint32_t mk_entry(uint32_t cl, uint32_t eb, uint32_t kind, uint32_t base)
+{
+    return cl | (eb << 4) | (kind << 8) | (base << 16);
+}
+enum : int { T_CODES = 0, T_LENS = 1, T_DISTS = 2 };
+
+constexpr int LIT_ROOT = 10;
+constexpr int DIST_ROOT = 9;
+constexpr int CL_ROOT = 7;
+constexpr int IN_DW = 512;    // staged input window, dwords
+constexpr int TOK_CAP = 256;  // token ring capacity
+
+// token: [8:0] match length (0 = literal), [31:9] literal byte or match distance
+__device__ __forceinline__ uint32_t tok_lit(uint32_t b) { return b << 9; }
+__device__ __forceinline__ uint32_t tok_match(uint32_t len, uint32_t dist) { return len | (dist << 9); }
+
+struct HuffMeta {
+    uint32_t limit15[16];  // [l] = end (exclusive) of the 15-bit-aligned code space of lengths <= l; [0] = 0
+    uint32_t offs[16];     // [l] = index in sorted[] of the first symbol of length l
+    uint32_t maxlen;
+};
+
+struct alignas(16) WaveLds {
+    uint32_t lit_lut[1 << LIT_ROOT];
+    uint32_t dist_lut[1 << DIST_ROOT];
+    uint32_t lit_sorted[288];
+    uint32_t dist_sorted[32];
+    uint32_t inbuf[IN_DW];
+    uint32_t tok[TOK_CAP];
+    uint32_t cl_lut[1 << CL_ROOT];
+    uint32_t cl_sorted[20];
+    HuffMeta lit_h, dist_h, cl_h;
+    uint32_t count[16];
+    uint8_t lens[320];
+};
+
+// RFC 1951 sec. 3.2.5, closed forms of the base/extra tables
+__device__ __forceinline__ uint32_t make_entry(int type, uint32_t sym, uint32_t len)
+{
+    if (type == T_CODES) return mk_entry(len, 0, K_LIT, sym);
+    if (type == T_LENS) {
+        if (sym < 256) return mk_entry(len, 0, K_LIT, sym);
+        if (sym == 256) return mk_entry(len, 0, K_EOB, 0);
+        if (sym >= 286) return mk_entry(len, 0, K_BAD, 0);
+        uint32_t s = sym - 257;
+        if (s < 8) return mk_entry(len, 0, K_LEN, 3 + s);
+        if (s == 28) return mk_entry(len, 0, K_LEN, 258);
+        uint32_t eb = (s >> 2) - 1;
+        return mk_entry(len, eb, K_LEN, 3 + ((4 + (s & 3)) << eb));
+    }
+    if (sym >= 30) return mk_entry(len, 0, K_BAD, 0);
+    if (sym < 4) return mk_entry(len, 0, K_LEN, 1 + sym);
+    uint32_t eb = (sym >> 1) - 1;
+    return mk_entry(len, eb, K_LEN, 1 + ((2 + (sym & 1)) << eb));
+}
+
+// Canonical lookup: x15 = next 15 stream bits, first bit in bit 14 (MSB-first code value).
+__device__ __forceinline__ uint32_t canon_lookup(const HuffMeta &H, const uint32_t *sorted, uint32_t x15)
+{
+    if (x15 >= H.limit15[15]) return mk_entry(H.maxlen ? H.maxlen : 1, 0, K_BAD, 0);
+    uint32_t l = 1;
+#pragma unroll
+    for (int j = 1; j < 15; j++) l += (x15 >= H.limit15[j]) ? 1u : 0u;
+    return sorted[H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l))];
+}
+
+// Build a canonical Huffman decode table from code lengths (RFC 1951 sec. 3.2.2) with zlib's
+// acceptance rules.  Wave-cooperative; lens[] lives in LDS.  Returns 0 or -1 (uniform).
+__device__ int build_table(WaveLds &L, const uint8_t *lens, int n, int type, int root, uint32_t *lut, uint32_t *sorted,
+                           HuffMeta &H)
+{
+    const uint32_t lane = lane_id();
+    if (lane < 16) L.count[lane] = 0;
+    WSYNC();
+    for (int s = lane; s < n; s += 64) {
+        uint32_t l = lens[s];
+        if (l) atomicAdd(&L.count[l], 1u);
+    }
+    WSYNC();
+    uint32_t code = 0, off = 0, maxlen = 0, mynext = 0;
+    int left = 1;
+    bool over = false;
+    for (uint32_t l = 1; l <= 15; l++) {
+        uint32_t c = L.count[l];
+        if (c) maxlen = l;
+        left = (left << 1) - (int)c;
+        if (left < 0) over = true;
+        if (lane == l) mynext = off;
+        if (lane == 0) H.offs[l] = off;
+        off += c;
+        code += c;
+        if (lane == 0) H.limit15[l] = code << (15 - l);
+        code <<= 1;
+    }
+    if (lane == 0) {
+        H.limit15[0] = 0;
+        H.offs[0] = 0;
+        H.maxlen = maxlen;
+    }
+    if (maxlen == 0) {
+        // empty set: zlib accepts it and every code is invalid (a code-length code made only of
+        // zeros reads as symbol 0 of length 1)
+        uint32_t e = type == T_CODES ? mk_entry(1, 0, K_LIT, 0) : mk_entry(1, 0, K_BAD, 0);
+        for (int i = lane; i < (1 << root); i += 64) lut[i] = e;
+        WSYNC();
+        return 0;
+    }
+    if (over) return -1;
+    if (left > 0 && (type == T_CODES || maxlen != 1)) return -1;
+    // stable counting sort by (length, symbol)
+    for (int base = 0; base < n; base += 64) {
+        int s = base + (int)lane;
+        uint32_t l = s < n ? lens[s] : 0;
+        for (uint32_t ll = 1; ll <= maxlen; ll++) {
+            uint64_t m = __ballot(l == ll);
+            uint32_t bp = rdlane(mynext, ll);
+            if (l == ll) sorted[bp + __popcll(m & lanemask_lt())] = make_entry(type, (uint32_t)s, l);
+            if (lane == ll) mynext += __popcll(m);
+        }
+    }
+    WSYNC();
+    // entry-centric fill of the root table
+    for (uint32_t idx = lane; idx < (1u << root); idx += 64) {
+        uint32_t x15 = __brev(idx) >> 17;
+        uint32_t e;
+        if (x15 >= H.limit15[15]) e = mk_entry(maxlen, 0, K_BAD, 0);
+        else if (x15 >= H.limit15[root]) e = 0;
+        else e = canon_lookup(H, sorted, x15);
+        lut[idx] = e;
+    }
+    WSYNC();
+    return 0;
+}
+
+struct InWin {
+    const uint32_t *g32;  // dword-aligned base covering the unit's bytes
+    uint32_t total_dw;    // dwords that contain at least one byte of the unit
+    uint32_t win0;        // dword index held in inbuf[0]
+};
+
+__device__ __forceinline__ void win_load(WaveLds &L, InWin &w, uint32_t dw_start)
+{
+    WSYNC();
+    w.win0 = dw_start;
+    for (uint32_t k = lane_id(); k < IN_DW; k += 64) {
+        uint32_t i = dw_start + k;
+        L.inbuf[k] = i < w.total_dw ? w.g32[i] : 0u;
+    }
+    WSYNC();
+}
+
+// make sure the dwords covering `span` bits from `pos` (plus one for the funnel shift) are staged
+__device__ __forceinline__ void win_ensure(WaveLds &L, InWin &w, uint32_t pos, uint32_t span = 64)
+{
+    uint32_t d = pos >> 5;
+    if (d < w.win0 || d + ((span + 62u) >> 5) + 1u > w.win0 + IN_DW) win_load(L, w, d);
+}
+
+// 64 stream bits starting at `pos` (lo = first 32)
+__device__ __forceinline__ void win_bits(const WaveLds &L, const InWin &w, uint32_t pos, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t D = (pos >> 5) - w.win0, sh = pos & 31;
+    uint32_t d0 = L.inbuf[D], d1 = L.inbuf[D + 1], d2 = L.inbuf[D + 2];
+    lo = __builtin_amdgcn_alignbit(d1, d0, sh);
+    hi = __builtin_amdgcn_alignbit(d2, d1, sh);
+}
+
+__device__ __forceinline__ uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
+
+// LZ77 execution of the buffered tokens.  Returns false when decoding must stop (error / output full).
+__device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status)
+{
+    const uint32_t lane = lane_id();
+    for (uint32_t g = 0; g < ntok; g += 64) {
+        uint32_t i = g + lane;
+        bool valid = i < ntok;
+        uint32_t t = valid ? L.tok[i] : 0u;
+        uint32_t len = t & 0x1ffu, val = t >> 9;
+        uint32_t olen = valid ? (len ? len : 1u) : 0u;
+        uint32_t incl = wave_incl_scan(olen);
+        uint32_t start = opos + incl - olen;
+        // "invalid distance too far back": distance reaches before the first output byte
+        uint64_t badm = __ballot(valid && len && val > start);
+        int32_t err = 0;
+        if (badm) {
+            uint32_t fb = (uint32_t)__ffsll((long long)badm) - 1;
+            if (lane >= fb) {
+                valid = false;
+                olen = 0;
+            }
+            err = Z_DATA_ERROR;
+        }
+        uint32_t total = badm ? rdlane(start, (uint32_t)__ffsll((long long)badm) - 1) - opos : rdlane(incl, 63u);
+        if (valid && !len && start < cap) gout[start] = (uint8_t)val;
+        uint64_t mm = __ballot(valid && len);
+        while (mm) {
+            uint32_t m = (uint32_t)__ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            uint32_t mstart = rdlane(start, m), mlen = rdlane(len, m), mdist = rdlane(val, m);
+            const uint8_t *src = gout + (mstart - mdist);
+            for (uint32_t j = lane; j < mlen; j += 64) {
+                uint32_t so = mdist >= mlen ? j : j % mdist;
+                uint8_t b = src[so];
+                if (mstart + j < cap) gout[mstart + j] = b;
+            }
+        }
+        opos += total;
+        if (opos > cap) {
+            opos = cap;
+            status = CHIP_NEED_OUTPUT;
+            return false;
+        }
+        if (err) {
+            status = err;
+            return false;
+        }
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
+{
+    __shared__ WaveLds L;
+    const uint32_t u = blockIdx.x;
+    if (u >= a.n) return;
+    const uint32_t lane = lane_id();
+
+    const uint8_t *gin = a.in_base + a.in_off[u];
+    const uint32_t in_len = a.in_len[u];
+    uint8_t *gout = a.out_base + a.out_off[u];
+    const uint32_t cap = a.out_cap[u];
+
+    InWin w;
+    const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);
+    w.g32 = (const uint32_t *)(gin - mis);
+    w.total_dw = (mis + in_len + 3u) >> 2;
+    w.win0 = 0xffffffffu;
+    const uint32_t start_bit = mis * 8u;
+    const uint32_t end_bit = start_bit + in_len * 8u;
+
+    uint32_t pos = start_bit;
+    uint32_t opos = 0;
+    uint32_t ntok = 0;
+    int32_t status = ST_RUNNING;
+    bool last = false;
+    int tables = 0;  // 0 none, 1 fixed, 2 dynamic
+
+    win_load(L, w, pos >> 5);
+
+    while (status == ST_RUNNING) {
+        if (last) {
+            status = CHIP_FINISHED;
+            break;
+        }
+        win_ensure(L, w, pos);
+        if (pos + 3 > end_bit) {
+            status = CHIP_NEED_INPUT;
+            break;
+        }
+        uint32_t lo, hi;
+        win_bits(L, w, pos, lo, hi);
+        last = lo & 1u;
+        uint32_t type = (lo >> 1) & 3u;
+        pos += 3;
+        if (type == 0) {
+            // stored block, RFC 1951 sec. 3.2.4
+            pos = (pos + 7u) & ~7u;
+            if (pos + 32 > end_bit) {
+                status = CHIP_NEED_INPUT;
+                break;
+            }
+            win_ensure(L, w, pos);
+            win_bits(L, w, pos, lo, hi);
+            uint32_t blen = lo & 0xffffu, nlen = lo >> 16;
+            if (blen != (nlen ^ 0xffffu)) {
+                status = Z_DATA_ERROR;
+                break;
+            }
+            pos += 32;
+            uint32_t avail = (end_bit - pos) >> 3;
+            uint32_t room = cap - opos;
+            uint32_t ncopy = blen < avail ? blen : avail;
+            if (ncopy > room) ncopy = room;
+            const uint8_t *src = gin + ((pos - start_bit) >> 3);
+            for (uint32_t j = lane; j < ncopy; j += 64) gout[opos + j] = src[j];
+            opos += ncopy;
+            pos += ncopy * 8u;
+            if (ncopy < blen) {
+                // zlib reports Z_OK here; compu calls it NeedInput when no input is left (mod.rs:476-479)
+                status = ncopy == avail ? CHIP_NEED_INPUT : CHIP_NEED_OUTPUT;
+                break;
+            }
+            continue;
+        }
+        if (type == 3) {
+            status = Z_DATA_ERROR;
+            break;
+        }
+        if (type == 1) {
+            if (tables != 1) {
+                for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                WSYNC();
+                build_table(L, L.lens, 288, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h);
+                if (lane < 32) L.lens[lane] = 5;
+                WSYNC();
+                build_table(L, L.lens, 32, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h);
+                tables = 1;
+            }
+        } else {
+            // dynamic block header, RFC 1951 sec. 3.2.7
+            tables = 2;
+            if (pos + 14 > end_bit) {
+                status = CHIP_NEED_INPUT;
+                break;
+            }
+            win_ensure(L, w, pos);
+            win_bits(L, w, pos, lo, hi);
+            uint32_t nlen = (lo & 31u) + 257, ndist = ((lo >> 5) & 31u) + 1, ncode = ((lo >> 10) & 15u) + 4;
+            pos += 14;
+            if (nlen > 286 || ndist > 30) {
+                status = Z_DATA_ERROR;
+                break;
+            }
+            if (pos + 3 * ncode > end_bit) {
+                status = CHIP_NEED_INPUT;
+                break;
+            }
+            win_ensure(L, w, pos, 128);
+            if (lane < 19) L.lens[lane] = 0;
+            WSYNC();
+            if (lane < ncode) {
+                static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+                uint32_t l2, h2;
+                win_bits(L, w, pos + 3 * lane, l2, h2);
+                L.lens[order[lane]] = (uint8_t)(l2 & 7u);
+            }
+            WSYNC();
+            pos += 3 * ncode;
+            if (build_table(L, L.lens, 19, T_CODES, CL_ROOT, L.cl_lut, L.cl_sorted, L.cl_h)) {
+                status = Z_DATA_ERROR;
+                break;
+            }
+            // code lengths of the two alphabets (sequential: each symbol's position depends on the previous)
+            uint32_t have = 0, total = nlen + ndist, prev = 0;
+            while (have < total) {
+                win_ensure(L, w, pos);
+                win_bits(L, w, pos, lo, hi);
+                uint32_t e = L.cl_lut[lo & 127u];
+                uint32_t cl = e & 15u, sym = e >> 16;
+                if (sym < 16) {
+                    if (pos + cl > end_bit) {
+                        status = CHIP_NEED_INPUT;
+                        break;
+                    }
+                    if (lane == 0) L.lens[have] = (uint8_t)sym;
+                    prev = sym;
+                    have++;
+                    pos += cl;
+                    continue;
+                }
+                uint32_t eb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+                if (pos + cl + eb > end_bit) {
+                    status = CHIP_NEED_INPUT;
+                    break;
+                }
+                uint32_t rep = (sym == 18 ? 11u : 3u) + bfe(lo, cl, eb);
+                uint32_t val = 0;
+                if (sym == 16) {
+                    if (have == 0) {
+                        status = Z_DATA_ERROR;
+                        break;
+                    }
+                    val = prev;
+                } else {
+                    prev = 0;
+                }
+                if (have + rep > total) {
+                    status = Z_DATA_ERROR;
+                    break;
+                }
+                for (uint32_t j = lane; j < rep; j += 64) L.lens[have + j] = (uint8_t)val;
+                have += rep;
+                pos += cl + eb;
+            }
+            if (status != ST_RUNNING) break;
+            WSYNC();
+            if (L.lens[256] == 0) {
+                status = Z_DATA_ERROR;
+                break;
+            }
+            if (build_table(L, L.lens, (int)nlen, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h) ||
+                build_table(L, L.lens + nlen, (int)ndist, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h)) {
+                status = Z_DATA_ERROR;
+                break;
+            }
+        }
+        // ---- token loop --------------------------------------------------------------------
+        for (;;) {
+            win_ensure(L, w, pos);
+            win_bits(L, w, pos, lo, hi);
+            uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
+            if ((e & 15u) == 0) e = canon_lookup(L.lit_h, L.lit_sorted, __brev(lo) >> 17);
+            uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+            uint32_t n1 = cl + eb;
+            if (pos + n1 > end_bit) {
+                status = CHIP_NEED_INPUT;
+                break;
+            }
+            if (kind == K_LIT) {
+                if (lane == 0) L.tok[ntok] = tok_lit(e >> 16);
+                pos += cl;
+            } else if (kind == K_EOB) {
+                pos += cl;
+                break;
+            } else if (kind == K_BAD) {
+                status = Z_DATA_ERROR;
+                break;
+            } else {
+                uint32_t len = (e >> 16) + bfe(lo, cl, eb);
+                uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+                uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
+                if ((e2 & 15u) == 0) e2 = canon_lookup(L.dist_h, L.dist_sorted, __brev(w2) >> 17);
+                uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
+                uint32_t n2 = cl2 + eb2;
+                if (pos + n1 + n2 > end_bit) {
+                    status = CHIP_NEED_INPUT;
+                    break;
+                }
+                if (((e2 >> 8) & 3u) == K_BAD) {
+                    status = Z_DATA_ERROR;
+                    break;
+                }
+                uint32_t dist = (e2 >> 16) + bfe(w2, cl2, eb2);
+                if (lane == 0) L.tok[ntok] = tok_match(len, dist);
+                pos += n1 + n2;
+            }
+            ntok++;
+            if (ntok == TOK_CAP) {
+                WSYNC();
+                int32_t st2 = ST_RUNNING;
+                bool ok = flush_tokens(L, ntok, gout, opos, cap, st2);
+                ntok = 0;
+                WSYNC();
+                if (!ok) {
+                    status = st2;
+                    break;
+                }
+            }
+        }
+    }
+    // tokens decoded before a stop condition are still output (zlib writes everything it decoded)
+    if (ntok) {
+        WSYNC();
+        int32_t st2 = ST_RUNNING;
+        if (!flush_tokens(L, ntok, gout, opos, cap, st2)) status = st2;
+    }
+    if (lane == 0) {
+        uint32_t used = (pos - start_bit + 7u) >> 3;
+        if (used > in_len) used = in_len;
+        a.out_len[u] = opos;
+        a.in_used[u] = status == CHIP_NEED_INPUT ? in_len : used;
+        a.status[u] = status;
+    }
+}
+
+hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(inflate_kernel, dim3(a.n), dim3(64), 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace chip

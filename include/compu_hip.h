@@ -1,0 +1,170 @@
+/*
+ * compu_hip.h -- C ABI of the MI355X (gfx950) batched compression backend for compu.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.  Each entry point
+ * names the reference interface it replaces (paths relative to the compu crate root).  A Rust
+ * `hip` Interface variant binds these 1:1 (INTEGRATION.md shows the glue).
+ *
+ * Everything here runs on the GPU.  There is no CPU codec behind this library: if no HIP device
+ * is usable the constructors return NULL / the batch calls return CHIP_E_NO_DEVICE.
+ */
+#ifndef COMPU_HIP_H
+#define COMPU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- shared enums -------------------------------------------------------------------------- */
+
+/* decoder::DecodeStatus, src/decoder/mod.rs:139-146 (same order) */
+enum { CHIP_NEED_INPUT = 0, CHIP_NEED_OUTPUT = 1, CHIP_FINISHED = 2 };
+
+/* encoder::EncodeOp src/encoder/mod.rs:12-23, encoder::EncodeStatus src/encoder/mod.rs:27-38 */
+enum { CHIP_OP_PROCESS = 0, CHIP_OP_FLUSH = 1, CHIP_OP_FINISH = 2 };
+enum { CHIP_ENC_CONTINUE = 0, CHIP_ENC_NEED_OUTPUT = 1, CHIP_ENC_FINISHED = 2, CHIP_ENC_ERROR = 3 };
+
+/* decoder::ZlibMode src/decoder/zlib_common.rs:4-15 and encoder ZlibMode
+ * src/encoder/zlib_common.rs:28-37 use zlib's windowBits values; zstd gets its own tag. */
+enum {
+    CHIP_FMT_DEFLATE = -15,
+    CHIP_FMT_ZLIB = 15,
+    CHIP_FMT_GZIP = 31,
+    CHIP_FMT_AUTO = 47, /* decoder only: zlib or gzip, src/decoder/zlib_common.rs:11-14 */
+    CHIP_FMT_ZSTD = 100
+};
+
+/* decoder::Detection src/decoder/mod.rs:9-21; CHIP_DETECT_NONE is Rust's `None` (too few bytes) */
+enum { CHIP_DETECT_NONE = -1, CHIP_DETECT_ZSTD = 0, CHIP_DETECT_GZIP = 1, CHIP_DETECT_ZLIB = 2, CHIP_DETECT_UNKNOWN = 3 };
+
+/* library-level failures of the batch calls (not codec errors) */
+enum { CHIP_OK = 0, CHIP_E_NO_DEVICE = -100, CHIP_E_INVALID = -101, CHIP_E_LAUNCH = -102, CHIP_E_NOMEM = -103 };
+
+/* decoder::Decode src/decoder/mod.rs:150-157.  status is Ok(DecodeStatus) when err == 0 and
+ * Err(DecodeError(err)) otherwise (err = zlib's negative code, or -(ZSTD_ErrorCode)). */
+typedef struct {
+    size_t input_remain;
+    size_t output_remain;
+    int32_t status;
+    int32_t err;
+} chip_decode_result;
+
+/* encoder::Encode src/encoder/mod.rs:42-49 */
+typedef struct {
+    size_t input_remain;
+    size_t output_remain;
+    int32_t status;
+} chip_encode_result;
+
+/* ---- device / library ---------------------------------------------------------------------- */
+
+/* Number of usable gfx950 devices (0 if none); never initialises more than the HIP runtime. */
+int chip_device_count(void);
+/* Select the device used by subsequent calls of this thread (hipSetDevice semantics). */
+int chip_set_device(int device);
+const char *chip_version(void);
+
+/* src/mem.rs:27-76 routes every codec allocation through compu_malloc/compu_free.  Host-side
+ * state of this backend goes through the same hooks when installed (signatures of
+ * compu_malloc_with_state / compu_free_with_state, src/mem.rs:52-57,74-76); device memory comes
+ * from hipMalloc and staging memory from hipHostMalloc. */
+typedef void *(*chip_malloc_fn)(void *opaque, size_t size);
+typedef void (*chip_free_fn)(void *opaque, void *ptr);
+void chip_set_allocator(chip_malloc_fn malloc_fn, chip_free_fn free_fn, void *opaque);
+
+/* Device and pinned-host buffers (north star: src/buffer.rs grows pinned-host + device types). */
+void *chip_device_alloc(size_t size);
+void chip_device_free(void *ptr);
+void *chip_pinned_alloc(size_t size);
+void chip_pinned_free(void *ptr);
+int chip_memcpy_h2d(void *dst_dev, const void *src_host, size_t size, void *stream);
+int chip_memcpy_d2h(void *dst_host, const void *src_dev, size_t size, void *stream);
+int chip_stream_sync(void *stream);
+
+/* ---- streaming decoder: mirrors decoder::Interface, src/decoder/mod.rs:160-166 --------------- */
+
+typedef struct chip_decoder chip_decoder;
+
+typedef struct {
+    int32_t window_log_max; /* ZstdOptions::window_log, src/decoder/zstd.rs:22-47; 0 = default */
+    int32_t device;         /* HIP device ordinal, -1 = current */
+} chip_decoder_opts;
+
+/* Interface::zlib_ng(mode) src/decoder/zlib_ng.rs:61-90 / Interface::zstd(opts)
+ * src/decoder/zstd.rs:81-94.  NULL on failure (the Rust side maps NULL to None). */
+chip_decoder *chip_decoder_new(int format, const chip_decoder_opts *opts);
+/* decode_fn: src/decoder/zlib_ng.rs:94-96 (+ macro src/decoder/mod.rs:459-486),
+ * src/decoder/zstd.rs:98-136.  `in`/`out` are host pointers borrowed for the call only. */
+chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
+/* reset_fn: src/decoder/zlib_ng.rs:99-108, src/decoder/zstd.rs:139-148.  Returns the instance
+ * to keep using (compu replaces its pointer with the returned one, src/decoder/mod.rs:433-441). */
+chip_decoder *chip_decoder_reset(chip_decoder *d);
+/* drop_fn: src/decoder/zlib_ng.rs:111-115, src/decoder/zstd.rs:151-156 */
+void chip_decoder_free(chip_decoder *d);
+/* describe_error_fn: src/decoder/zlib_ng.rs:118-123 (zError), src/decoder/zstd.rs:159-164
+ * (ZSTD_getErrorName).  Never NULL for code 0 (tests/decoder.rs:74-76). */
+const char *chip_decoder_strerror(int format, int32_t code);
+
+/* ---- batched decode: the hot path (additive API) -------------------------- */
+
+/*
+ * Decode n independent units in one launch, one wavefront per unit.  Every pointer is a DEVICE
+ * pointer.  Unit i reads in_base[in_off[i] .. +in_len[i]) and writes out_base[out_off[i] ..
+ * +out_cap[i]).  Results per unit:
+ *   out_len[i]  bytes written
+ *   in_used[i]  bytes of input consumed (trailing bytes after the stream are not counted)
+ *   status[i]   CHIP_FINISHED / CHIP_NEED_INPUT (stream truncated) / CHIP_NEED_OUTPUT (out_cap too
+ *               small), or a negative codec error with the meaning of DecodeError
+ *               (zlib: -3 data error; zstd: -(ZSTD_ErrorCode), e.g. -20 corruption, -22 checksum)
+ * in_base must be 4-byte aligned and its allocation padded to a multiple of 4 bytes.
+ * `format` is one CHIP_FMT_* for the whole batch.  `stream` is a hipStream_t (NULL = default
+ * stream); the call only enqueues work.  Returns CHIP_OK or a CHIP_E_* code.
+ * Replaces, per unit, the loop  Interface::zlib_ng(mode) -> decode -> reset
+ * (src/decoder/zlib_ng.rs:61-108, src/decoder/mod.rs:459-486).
+ */
+int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                      void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                      uint32_t *in_used, int32_t *status, void *stream);
+
+/* Detection::detect src/decoder/mod.rs:28-114 on the first bytes of each unit; kind[i] gets a
+ * CHIP_DETECT_* value.  Host form and batched device form. */
+int chip_detect(const uint8_t *bytes, size_t len);
+int chip_detect_batch(size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
+                      void *stream);
+
+/* ---- encoder: mirrors encoder::Interface, src/encoder/mod.rs:52-57 ---------------------------- */
+
+typedef struct chip_encoder chip_encoder;
+
+/* ZlibOptions src/encoder/zlib_common.rs:47-66 (the two bytes compu replays on reset,
+ * src/encoder/mod.rs:54,151,315, are {mode, compression}) */
+typedef struct {
+    int32_t mode;        /* CHIP_FMT_DEFLATE | CHIP_FMT_ZLIB | CHIP_FMT_GZIP (default Gzip, zlib_common.rs:33-37) */
+    int32_t compression; /* 0..9; this backend implements the level-1 class (greedy match + fixed Huffman) for 1..9 */
+    int32_t device;
+} chip_encoder_opts;
+
+/* Interface::zlib_ng(opts) src/encoder/zlib_ng.rs:50-87 */
+chip_encoder *chip_encoder_new(const chip_encoder_opts *opts);
+/* encode_fn src/encoder/zlib_ng.rs:90-92 (+ macro src/encoder/mod.rs:334-370) */
+chip_encode_result chip_encode(chip_encoder *e, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int op);
+/* reset_fn src/encoder/zlib_ng.rs:95-104 */
+chip_encoder *chip_encoder_reset(chip_encoder *e);
+/* drop_fn src/encoder/zlib_ng.rs:107-111 */
+void chip_encoder_free(chip_encoder *e);
+
+/* Batched level-1 encode of n independent units (device pointers, one wavefront per unit).
+ * out_len[i] = compressed size; status[i] = CHIP_ENC_FINISHED or CHIP_ENC_NEED_OUTPUT. */
+int chip_encode_batch(int format, int level, size_t n, const void *in_base, const uint64_t *in_off,
+                      const uint32_t *in_len, void *out_base, const uint64_t *out_off, const uint32_t *out_cap,
+                      uint32_t *out_len, int32_t *status, void *stream);
+/* Worst-case compressed size for in_len input bytes in `format` (sizing out_cap). */
+size_t chip_encode_bound(int format, size_t in_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

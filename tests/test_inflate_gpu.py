@@ -1,0 +1,138 @@
+"""Parity of the HIP inflate path (through the C ABI) against the oracle and the original bytes."""
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _pack(parts):
+    lens = np.array([len(p) for p in parts], dtype=np.int32)
+    offs = np.zeros(len(parts), dtype=np.int64)
+    if len(parts) > 1:
+        offs[1:] = np.cumsum(lens[:-1].astype(np.int64))
+    total = int(lens.astype(np.int64).sum())
+    buf = np.zeros(((total + 3) & ~3) + 4, np.uint8)
+    buf[:total] = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    return buf, offs, lens
+
+
+def run_batch(torch, fmt, parts, caps):
+    """Decode `parts` in one launch; returns (list of outputs, out_len, in_used, status) on the host."""
+    import compu_amd
+
+    buf, offs, lens = _pack(parts)
+    caps = np.asarray(caps, dtype=np.int32)
+    ooff = np.zeros(len(parts), dtype=np.int64)
+    if len(parts) > 1:
+        ooff[1:] = np.cumsum(((caps[:-1].astype(np.int64) + 15) & ~15))
+    total_out = int(ooff[-1] + caps[-1]) + 16
+    dev = "cuda:0"
+    d_in = torch.from_numpy(buf).to(dev)
+    d_out = torch.full((total_out,), 0xA5, dtype=torch.uint8, device=dev)
+    out_len, in_used, status = compu_amd.decode_batch(
+        fmt, d_in, torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev), d_out,
+        torch.from_numpy(ooff).to(dev), torch.from_numpy(caps).to(dev))
+    torch.cuda.synchronize()
+    h_out = d_out.cpu().numpy()
+    ol, iu, st = out_len.cpu().numpy(), in_used.cpu().numpy(), status.cpu().numpy()
+    outs = [bytes(h_out[ooff[i] : ooff[i] + ol[i]]) for i in range(len(parts))]
+    # bytes behind each unit's produced range must be untouched (poison intact)
+    for i in range(len(parts)):
+        tail = h_out[ooff[i] + ol[i] : ooff[i] + ((caps[i] + 15) & ~15)]
+        assert (tail == 0xA5).all(), f"unit {i}: wrote past out_len"
+    return outs, ol, iu, st
+
+
+def oracle_batch(mode, parts, caps):
+    from oracle import oracle as O
+
+    res = []
+    for p, c in zip(parts, caps):
+        d = O.InflateDecoder(mode)
+        got, ir, orr, st, err = d.decode(p, int(c))
+        res.append((got, len(p) - ir, err if err else st))
+    return res
+
+
+def _mk(kind, n, rnd, alice):
+    if kind == 0:
+        return rnd.randbytes(n)
+    if kind == 1:
+        s = rnd.randrange(0, max(1, len(alice) - n))
+        return alice[s : s + n]
+    if kind == 2:
+        return bytes(rnd.choice(b"ab") for _ in range(n))
+    if kind == 3:
+        return b"\0" * n
+    return bytes(min(255, int(rnd.expovariate(0.05))) for _ in range(n))
+
+
+def test_raw_deflate_small_units(gpu, alice):
+    rnd = random.Random(11)
+    datas, parts = [], []
+    for it in range(300):
+        n = rnd.choice([0, 1, 2, 3, 10, 100, 1000, 5000, 20000, 65536, 70000])
+        data = _mk(rnd.randrange(5), n, rnd, alice)
+        level = rnd.choice([0, 1, 4, 6, 9])
+        strat = rnd.choice([0, 0, 0, 1, 2, 3, 4])
+        co = zlib.compressobj(level, zlib.DEFLATED, -15, rnd.choice([1, 8, 9]), strat)
+        comp = co.compress(data[: n // 2]) + (co.flush(zlib.Z_SYNC_FLUSH) if rnd.random() < 0.3 else b"") + co.compress(data[n // 2 :]) + co.flush()
+        datas.append(data)
+        parts.append(comp)
+    caps = [len(d) + rnd.choice([0, 0, 7, 100]) for d in datas]
+    outs, ol, iu, st = run_batch(gpu, -15, parts, caps)
+    ref = oracle_batch(-15, parts, caps)
+    for i in range(len(parts)):
+        assert st[i] == 2, (i, st[i])
+        assert outs[i] == datas[i], i
+        assert outs[i] == ref[i][0] and iu[i] == ref[i][1] and st[i] == ref[i][2], i
+
+
+def test_raw_deflate_64k_synthetic_units(gpu):
+    from bench_support import synth
+
+    n = 256
+    pay = synth.payloads(n)
+    for kind in ("stored", "fixed", "dynamic", "level1"):
+        packed, offs, lens = synth.deflate_units(pay, n, kind=kind)
+        parts = [bytes(packed[int(offs[i]) : int(offs[i]) + int(lens[i])]) for i in range(n)]
+        outs, ol, iu, st = run_batch(gpu, -15, parts, [65536] * n)
+        assert (st == 2).all(), (kind, st[st != 2][:8])
+        assert (ol == 65536).all()
+        assert (iu == lens).all()
+        assert b"".join(outs) == pay.tobytes(), kind
+
+
+def test_truncated_corrupt_and_small_caps_match_oracle(gpu, alice):
+    rnd = random.Random(5)
+    parts, caps = [], []
+    for it in range(400):
+        n = rnd.choice([50, 500, 5000, 30000])
+        data = _mk(rnd.choice([1, 2, 4]), n, rnd, alice)
+        co = zlib.compressobj(rnd.choice([0, 1, 6, 9]), zlib.DEFLATED, -15, 8, rnd.choice([0, 4]))
+        comp = bytearray(co.compress(data) + co.flush())
+        mode = rnd.randrange(4)
+        if mode == 0:  # flip a bit
+            k = rnd.randrange(len(comp))
+            comp[k] ^= 1 << rnd.randrange(8)
+        elif mode == 1:  # truncate
+            comp = comp[: rnd.randrange(len(comp))]
+        elif mode == 2:  # trailing garbage
+            comp += rnd.randbytes(rnd.randrange(1, 9))
+        cap = n if mode != 3 else rnd.randrange(0, n)  # mode 3: output too small
+        parts.append(bytes(comp))
+        caps.append(cap)
+    outs, ol, iu, st = run_batch(gpu, -15, parts, caps)
+    ref = oracle_batch(-15, parts, caps)
+    for i in range(len(parts)):
+        r_out, r_used, r_st = ref[i]
+        assert st[i] == r_st, (i, st[i], r_st)
+        assert outs[i] == r_out, (i, len(outs[i]), len(r_out))
+        if r_st == 2:
+            assert iu[i] == r_used, (i, iu[i], r_used)
