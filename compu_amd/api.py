@@ -242,7 +242,9 @@ class Vec:
     """A byte vector with explicit capacity (Rust's Vec<u8>: len() <= capacity())."""
 
     def __init__(self, capacity=0):
-        self._buf = bytearray(capacity)
+        import numpy as np
+
+        self._buf = np.zeros(capacity, np.uint8)
         self._len = 0
 
     @classmethod
@@ -253,20 +255,24 @@ class Vec:
         return self._len
 
     def capacity(self):
-        return len(self._buf)
+        return self._buf.size
 
     def try_reserve_exact(self, additional):
+        import numpy as np
+
         need = self._len + additional
-        if need > len(self._buf):
-            self._buf.extend(bytes(need - len(self._buf)))
+        if need > self._buf.size:
+            grown = np.zeros(need, np.uint8)
+            grown[: self._len] = self._buf[: self._len]
+            self._buf = grown
 
     reserve = try_reserve_exact
 
     def spare_capacity_len(self):
-        return len(self._buf) - self._len
+        return self._buf.size - self._len
 
     def set_len(self, n):
-        assert n <= len(self._buf)
+        assert n <= self._buf.size
         self._len = n
 
     def clear(self):
@@ -276,12 +282,14 @@ class Vec:
         self._len = min(self._len, n)
 
     def extend_from_slice(self, data):
+        import numpy as np
+
         self.try_reserve_exact(len(data))
-        self._buf[self._len : self._len + len(data)] = data
+        self._buf[self._len : self._len + len(data)] = np.frombuffer(bytes(data), dtype=np.uint8)
         self._len += len(data)
 
     def __bytes__(self):
-        return bytes(self._buf[: self._len])
+        return self._buf[: self._len].tobytes()
 
     def __eq__(self, other):
         return bytes(self) == bytes(other)
@@ -289,26 +297,27 @@ class Vec:
 
 def _in_ptr(data):
     """(keepalive, pointer, length) for a read-only bytes-like; never a NULL pointer (mod.rs:283)."""
-    if isinstance(data, (bytes, bytearray)):
-        n = len(data)
-        if n == 0:
-            keep = C.create_string_buffer(1)
-            return keep, C.cast(keep, C.c_void_p), 0
-        if isinstance(data, bytes):
-            keep = data
-            return keep, C.cast(C.c_char_p(keep), C.c_void_p), n
-        keep = (C.c_uint8 * n).from_buffer(data)
-        return keep, C.cast(keep, C.c_void_p), n
-    mv = memoryview(data).cast("B")
-    return _in_ptr(bytes(mv))
+    import numpy as np
+
+    if not isinstance(data, (bytes, bytearray)):
+        data = bytes(memoryview(data).cast("B"))
+    n = len(data)
+    if n == 0:
+        keep = np.zeros(1, np.uint8)
+        return keep, C.c_void_p(keep.ctypes.data), 0
+    keep = np.frombuffer(data, dtype=np.uint8)
+    return keep, C.c_void_p(keep.ctypes.data), n
 
 
 def _out_ptr(buf, offset, length):
+    import numpy as np
+
     if length == 0:
-        keep = C.create_string_buffer(1)
-        return keep, C.cast(keep, C.c_void_p)
-    keep = (C.c_uint8 * length).from_buffer(buf, offset)
-    return keep, C.cast(keep, C.c_void_p)
+        keep = np.zeros(1, np.uint8)
+        return keep, C.c_void_p(keep.ctypes.data)
+    keep = buf if isinstance(buf, np.ndarray) else np.frombuffer(buf, dtype=np.uint8)
+    assert keep.flags.writeable and offset + length <= keep.size
+    return keep, C.c_void_p(keep.ctypes.data + offset)
 
 
 # ---- Decoder ---------------------------------------------------------------------------------
@@ -496,11 +505,13 @@ class Buffer:
     """Fixed-size buffer with a cursor (src/buffer.rs:1-49)."""
 
     def __init__(self, n):
-        self._buf = bytearray(n)
+        import numpy as np
+
+        self._buf = np.zeros(n, np.uint8)
         self.cursor = 0
 
     def data(self):
-        return bytes(self._buf[: self.cursor])
+        return self._buf[: self.cursor].tobytes()
 
     def consume(self):
         self.cursor = 0

@@ -348,7 +348,7 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
         r.status = CHIP_FINISHED;
         return r;
     }
-    const bool stream_end_known = d->decoded && (d->k_status == CHIP_FINISHED || d->k_status < 0 || d->k_status == Z_NEED_DICT);
+    const bool stream_end_known = d->decoded && (d->k_status == CHIP_FINISHED || d->k_status < 0 || d->k_status == CHIP_NEED_DICT);
     size_t taken = 0;
     if (!stream_end_known && in_len) {
         if (!dec_reserve_in(d, d->h_in_len + in_len)) {
@@ -381,7 +381,7 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
     r.output_remain = out_len - n;
     // bytes of this call that lie behind the end of the stream go back to the caller
     size_t giveback = 0;
-    if (d->k_status == CHIP_FINISHED || d->k_status < 0) {
+    if (d->k_status == CHIP_FINISHED || d->k_status < 0 || d->k_status == CHIP_NEED_DICT) {
         size_t trailing = d->h_in_len - d->k_in_used;
         giveback = trailing < taken ? trailing : taken;
         d->h_in_len -= giveback;
@@ -400,7 +400,7 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
         r.status = (in_len == 0 && n == 0) ? CHIP_NEED_OUTPUT : CHIP_NEED_INPUT;
     } else {
         r.status = -1;
-        r.err = d->k_status;
+        r.err = d->k_status == CHIP_NEED_DICT ? Z_NEED_DICT : d->k_status;
     }
     return r;
 }

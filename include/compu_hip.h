@@ -22,6 +22,11 @@ extern "C" {
 
 /* decoder::DecodeStatus, src/decoder/mod.rs:139-146 (same order) */
 enum { CHIP_NEED_INPUT = 0, CHIP_NEED_OUTPUT = 1, CHIP_FINISHED = 2 };
+/* Batch status only: the zlib header asks for a preset dictionary.  zlib answers Z_NEED_DICT (+2),
+ * which compu passes through as Err(DecodeError(2)) (src/decoder/mod.rs:482); the value 2 is taken
+ * by CHIP_FINISHED in the per-unit status array, hence a code of its own.  chip_decode() reports
+ * it as err = 2 like the reference. */
+enum { CHIP_NEED_DICT = 3 };
 
 /* encoder::EncodeOp src/encoder/mod.rs:12-23, encoder::EncodeStatus src/encoder/mod.rs:27-38 */
 enum { CHIP_OP_PROCESS = 0, CHIP_OP_FLUSH = 1, CHIP_OP_FINISH = 2 };
@@ -117,7 +122,7 @@ const char *chip_decoder_strerror(int format, int32_t code);
  *   out_len[i]  bytes written
  *   in_used[i]  bytes of input consumed (trailing bytes after the stream are not counted)
  *   status[i]   CHIP_FINISHED / CHIP_NEED_INPUT (stream truncated) / CHIP_NEED_OUTPUT (out_cap too
- *               small), or a negative codec error with the meaning of DecodeError
+ *               small) / CHIP_NEED_DICT, or a negative codec error with the meaning of DecodeError
  *               (zlib: -3 data error; zstd: -(ZSTD_ErrorCode), e.g. -20 corruption, -22 checksum)
  * in_base must be 4-byte aligned and its allocation padded to a multiple of 4 bytes.
  * `format` is one CHIP_FMT_* for the whole batch.  `stream` is a hipStream_t (NULL = default

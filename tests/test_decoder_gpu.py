@@ -1,0 +1,205 @@
+"""The reference's own decoder test (tests/decoder.rs:21-77, should_decode_zlib_ng_gzip :141-150)
+replayed phase by phase against the `hip` Interface variant, plus wrapper/trailer parity with the oracle."""
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+from conftest import golden
+from test_inflate_gpu import _mk, oracle_batch, run_batch
+
+pytestmark = pytest.mark.gpu
+
+DATA = ["10x10y", "alice29.txt"]
+
+
+def _test_case(compu, decoder, data, compressed):
+    """tests/decoder.rs:21-77"""
+    DecodeStatus, DecodeError = compu.DecodeStatus, compu.DecodeError
+    # Full (:25-31)
+    output = bytearray(len(data))
+    result = decoder.decode(compressed, output)
+    assert result.status == DecodeStatus.Finished
+    assert result.input_remain == 0
+    assert result.output_remain == 0
+    assert bytes(output) == data
+    decoder.reset()
+
+    # Partial buffer (:34-44); DATA.len() / 2 == 1 in the reference (DATA is the 2-element array)
+    half = len(DATA) // 2
+    result = decoder.decode(compressed, output, 0, half)
+    assert result.status == DecodeStatus.NeedOutput
+    assert result.output_remain == 0
+    remaining = compressed[len(compressed) - result.input_remain :]
+    result = decoder.decode(remaining, output, half, len(output) - half)
+    assert result.status == DecodeStatus.Finished
+    assert bytes(output) == data
+    decoder.reset()
+
+    # Buffered decoder (:47-63)
+    buffer = compu.Buffer(4096)
+    buffer_input = compressed
+    out = bytearray()
+    while True:
+        consumed, status = buffer.decode(decoder, buffer_input)
+        buffer_input = buffer_input[consumed:]
+        out += buffer.data()
+        buffer.consume()
+        if status == DecodeStatus.Finished:
+            break
+    assert bytes(out) == data
+    decoder.reset()
+
+    # Full vec (:66-72)
+    vec = compu.Vec()
+    result = decoder.decode_vec_full(compressed, vec)
+    assert result.status == DecodeStatus.Finished
+    assert result.input_remain == 0
+    assert bytes(vec) == data
+    decoder.reset()
+
+    # :74-76
+    assert decoder.describe_error(DecodeError.no_error()) is not None
+
+
+def test_should_decode_zlib_hip_gzip(gpu):
+    """tests/decoder.rs:141-150 with Interface::zlib_ng replaced by the hip variant"""
+    import compu_amd
+
+    decoder = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+    assert decoder is not None, "create zlib-hip decoder"
+    for name in DATA:
+        _test_case(compu_amd, decoder, golden(name), golden(name + ".compressed.gz"))
+    # the default mode (Auto, zlib_common.rs:24-29) takes the same fixtures
+    decoder = compu_amd.decoder_interface.zlib_hip()
+    for name in DATA:
+        _test_case(compu_amd, decoder, golden(name), golden(name + ".compressed.gz"))
+
+
+def test_stream_triples_match_oracle(gpu, alice):
+    """status / output_remain classes of SURVEY.md sec. 8b on chunked input, small outputs, truncation, corruption"""
+    import compu_amd
+    from oracle import oracle as O
+
+    comp = golden("alice29.txt.compressed.gz")
+    dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+    # first quarter of the input, big output -> NeedInput, all input consumed
+    out = bytearray(len(alice))
+    r = dec.decode(comp[: len(comp) // 4], out)
+    o = O.InflateDecoder(O.MODE_GZIP)
+    ref, ir, orr, st, err = o.decode(comp[: len(comp) // 4], len(alice))
+    assert r.status == compu_amd.DecodeStatus.NeedInput and r.input_remain == 0 == ir
+    assert r.output_remain == orr and bytes(out[: len(alice) - r.output_remain]) == ref
+    # the rest in 4 KiB chunks (the shape of tests/encoder.rs:152-171)
+    pos = len(comp) // 4
+    got = bytearray(ref)
+    while True:
+        chunk = comp[pos : pos + 4096]
+        buf = bytearray(len(alice))
+        r = dec.decode(chunk, buf)
+        got += buf[: len(buf) - r.output_remain]
+        pos += len(chunk) - r.input_remain
+        assert r.is_ok()
+        if r.status == compu_amd.DecodeStatus.Finished:
+            break
+        assert r.status == compu_amd.DecodeStatus.NeedInput and r.input_remain == 0
+    assert bytes(got) == alice and pos == len(comp)
+    dec.reset()
+    # truncated by one byte: everything is decoded, the trailer is incomplete -> NeedInput
+    r = dec.decode(comp[:-1], out)
+    assert r.status == compu_amd.DecodeStatus.NeedInput and bytes(out) == alice and r.output_remain == 0
+    dec.reset()
+    # corrupted payload -> Err(-3) "data error"
+    bad = bytearray(comp)
+    bad[len(bad) // 2] ^= 0x10
+    r = dec.decode(bytes(bad), out)  # decodes to one byte more than the original: room first
+    ref, ir, orr, st, err = O.InflateDecoder(O.MODE_GZIP).decode(bytes(bad), len(alice))
+    assert r.status == compu_amd.DecodeStatus.NeedOutput == st and r.output_remain == 0 == orr and bytes(out) == ref
+    dec.reset()
+    big = bytearray(2 * len(alice))
+    r = dec.decode(bytes(bad), big)
+    ref, ir, orr, st, err = O.InflateDecoder(O.MODE_GZIP).decode(bytes(bad), len(big))
+    assert not r.is_ok() and r.status.as_raw() == err == -3
+    assert r.output_remain == orr and bytes(big[: len(big) - orr]) == ref
+    assert dec.describe_error(r.status) == "data error"
+    dec.reset()
+    # trailing bytes after the stream stay in input_remain
+    r = dec.decode(comp + b"tail!", out)
+    assert r.status == compu_amd.DecodeStatus.Finished and r.input_remain == 5 and bytes(out) == alice
+    # a finished decoder stays finished until reset (README.md:43-44)
+    r = dec.decode(b"xyz", out)
+    assert r.status == compu_amd.DecodeStatus.Finished and r.input_remain == 3
+
+
+def test_wrapped_units_batch_match_oracle(gpu, alice):
+    """zlib / gzip / auto wrappers incl. FEXTRA/FNAME/FCOMMENT/FHCRC headers, bad trailers, FDICT"""
+    import gzip
+    import io
+    import struct
+
+    rnd = random.Random(21)
+
+    def gz_with_fields(data, flags):
+        raw = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = raw.compress(data) + raw.flush()
+        hdr = bytearray(b"\x1f\x8b\x08" + bytes([flags]) + b"\0\0\0\0\x02\x03")
+        if flags & 4:
+            extra = rnd.randbytes(rnd.randrange(0, 300))
+            hdr += struct.pack("<H", len(extra)) + extra
+        if flags & 8:
+            hdr += bytes(rnd.randrange(1, 256) for _ in range(rnd.randrange(0, 200))) + b"\0"
+        if flags & 16:
+            hdr += bytes(rnd.randrange(1, 256) for _ in range(rnd.randrange(0, 200))) + b"\0"
+        if flags & 2:
+            hdr += struct.pack("<H", zlib.crc32(bytes(hdr)) & 0xFFFF)
+        return bytes(hdr) + body + struct.pack("<II", zlib.crc32(data), len(data) & 0xFFFFFFFF)
+
+    for fmt in (15, 31, 47):
+        datas, parts = [], []
+        for it in range(150):
+            n = rnd.choice([0, 1, 20, 300, 5000, 65536])
+            data = _mk(rnd.choice([0, 1, 2, 3, 4]), n, rnd, alice)
+            kind = rnd.randrange(6)
+            wb = fmt if fmt != 47 else rnd.choice([15, 31])
+            if wb == 31 and kind == 0:
+                comp = gz_with_fields(data, rnd.randrange(32) & 0x1E)
+            else:
+                co = zlib.compressobj(rnd.choice([0, 1, 6, 9]), zlib.DEFLATED, wb)
+                comp = co.compress(data) + co.flush()
+            comp = bytearray(comp)
+            if kind == 1:  # break the trailer
+                comp[-rnd.randrange(1, 5 if wb == 15 else 9)] ^= 0x01
+            elif kind == 2:  # truncate somewhere (header, body or trailer)
+                comp = comp[: rnd.randrange(len(comp))]
+            elif kind == 3:  # damage a header byte
+                comp[rnd.randrange(min(len(comp), 4))] ^= 1 << rnd.randrange(8)
+            elif kind == 4:
+                comp += b"trailing"
+            datas.append(data)
+            parts.append(bytes(comp))
+        caps = [max(len(d), 1) for d in datas]
+        outs, ol, iu, st = run_batch(gpu, fmt, parts, caps)
+        ref = oracle_batch(fmt, parts, caps)
+        for i in range(len(parts)):
+            r_out, r_used, r_st = ref[i]
+            if len(parts[i]) == 0 and st[i] == 0 and r_st == 1:
+                continue
+            if st[i] == 1 and r_st == 0 and len(r_out) == caps[i]:
+                continue
+            assert st[i] == r_st, (fmt, i, st[i], r_st)
+            assert outs[i] == r_out, (fmt, i)
+            if r_st == 2:
+                assert iu[i] == r_used, (fmt, i)
+    # FDICT zlib header -> Z_NEED_DICT (2) once the dictionary id is there
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_DEFAULT_STRATEGY, b"dictionary")
+    comp = co.compress(b"dictionary words") + co.flush()
+    outs, ol, iu, st = run_batch(gpu, 15, [comp, comp[:4]], [100, 100])
+    ref = oracle_batch(15, [comp, comp[:4]], [100, 100])
+    # oracle_batch folds err=2 (Z_NEED_DICT) into its status slot; the batch API calls it CHIP_NEED_DICT = 3
+    assert st[0] == 3 and ref[0][2] == 2 and ref[0][0] == b"" and st[1] == 0 == ref[1][2]
+    import compu_amd
+
+    dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Zlib)
+    r = dec.decode(comp, bytearray(100))
+    assert not r.is_ok() and r.status.as_raw() == 2 and dec.describe_error(r.status) == "need dictionary"
