@@ -54,15 +54,23 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l)
 }
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 
-// inclusive prefix sum across the wave
+// DPP lane moves within the wave (gfx9 controls): lanes without a source keep 0
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+// inclusive prefix sum across the wave: Hillis-Steele inside each row of 16 lanes (row_shr:1,2,4,8),
+// then the row totals are carried over with row_bcast:15 (rows 1,3) and row_bcast:31 (rows 2,3)
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const uint32_t l = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = (uint32_t)__shfl_up((int)v, d, 64);
-        if (l >= (uint32_t)d) v += t;
-    }
+    v += dpp_or_zero<0x111>(v);
+    v += dpp_or_zero<0x112>(v);
+    v += dpp_or_zero<0x114>(v);
+    v += dpp_or_zero<0x118>(v);
+    v += dpp_or_zero<0x142, 0xa>(v);
+    v += dpp_or_zero<0x143, 0xc>(v);
     return v;
 }
 

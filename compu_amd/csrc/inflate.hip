@@ -27,8 +27,18 @@ enum : int { T_CODES = 0, T_LENS = 1, T_DISTS = 2 };
 constexpr int LIT_ROOT = 10;
 constexpr int DIST_ROOT = 9;
 constexpr int CL_ROOT = 7;
-constexpr int IN_DW = 512;    // staged input window, dwords
-constexpr int TOK_CAP = 256;  // token ring capacity
+// Speculative wave-parallel decode geometry: per super-round lane i owns S_BITS of the stream
+// starting at B + i*S_BITS and decodes O_BITS further into its successor's range so that the point
+// where the two decodes fall into step (the merge) can be proven.  S_BITS is an odd number of
+// dwords so that the 64 lanes' window reads hit distinct LDS banks.
+constexpr int S_BITS = 288;
+constexpr int O_BITS = 256;
+static_assert(O_BITS <= S_BITS && S_BITS % 32 == 0 && O_BITS % 32 == 0, "geometry");
+constexpr int BM_WORDS = (S_BITS + O_BITS) / 32;  // boundary bitmap words per lane
+constexpr int IN_DW = 592;     // staged input window, dwords: 64*S_BITS + O_BITS + one token + slack
+constexpr int TOK_CAP = 2304;  // token buffer capacity (also holds the boundary bitmaps during pass 1)
+static_assert(BM_WORDS * 64 <= TOK_CAP, "bitmaps alias the token buffer");
+static_assert(IN_DW * 32 >= 31 + 63 * S_BITS + S_BITS + O_BITS + 48 + 96, "window covers every lane's reads");
 
 // token: [8:0] match length (0 = literal), [31:9] literal byte or match distance
 __device__ __forceinline__ uint32_t tok_lit(uint32_t b) { return b << 9; }
@@ -335,7 +345,17 @@ __device__ int32_t parse_wrapper(uint32_t *tab, const uint8_t *gin, uint32_t ava
     return ST_RUNNING;
 }
 
-// LZ77 execution of the buffered tokens.  Returns false when decoding must stop (error / output full).
+// (off % d) for off, d < 512 without an integer divide
+__device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
+{
+    uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)d));
+    return off - q * d;
+}
+
+// LZ77 execution of tok[0..ntok): wave prefix sums give every token its output position; literals
+// are scattered with one byte store per 64 tokens; matches are copied several at a time, one
+// output byte per lane, as long as no source range reaches into bytes the same step writes.
+// Returns false when decoding must stop (error / output full).
 __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status)
 {
     const uint32_t lane = lane_id();
@@ -350,27 +370,62 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
         // "invalid distance too far back": distance reaches before the first output byte
         uint64_t badm = __ballot(valid && len && val > start);
         int32_t err = 0;
+        uint32_t total;
         if (badm) {
             uint32_t fb = (uint32_t)__ffsll((long long)badm) - 1;
             if (lane >= fb) {
                 valid = false;
-                olen = 0;
+                len = 0;
             }
+            total = rdlane(start, fb) - opos;
             err = Z_DATA_ERROR;
+        } else {
+            total = rdlane(incl, 63u);
         }
-        uint32_t total = badm ? rdlane(start, (uint32_t)__ffsll((long long)badm) - 1) - opos : rdlane(incl, 63u);
         if (valid && !len && start < cap) gout[start] = (uint8_t)val;
-        uint64_t mm = __ballot(valid && len);
-        while (mm) {
-            uint32_t m = (uint32_t)__ffsll((long long)mm) - 1;
-            mm &= mm - 1;
-            uint32_t mstart = rdlane(start, m), mlen = rdlane(len, m), mdist = rdlane(val, m);
-            if (mstart >= cap) break;  // everything from here on lies behind the output capacity
-            const uint8_t *src = gout + (mstart - mdist);
-            for (uint32_t j = lane; j < mlen; j += 64) {
-                uint32_t so = mdist >= mlen ? j : j % mdist;
-                uint8_t b = src[so];
-                if (mstart + j < cap) gout[mstart + j] = b;
+        uint32_t mlen = (valid && len) ? len : 0u;
+        uint64_t mm = __ballot(mlen != 0);
+        if (mm) {
+            uint32_t mbi = wave_incl_scan(mlen);  // match bytes up to and including this match
+            uint32_t mbx = mbi - mlen;
+            uint32_t srcend = start - val + (len < val ? len : val);  // end of the bytes actually read
+            while (mm) {
+                const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
+                const uint32_t d0 = rdlane(start, k0), b0 = rdlane(mbx, k0), l0 = rdlane(mlen, k0);
+                if (d0 >= cap) break;  // everything from here on lies behind the output capacity
+                if (l0 > 64) {
+                    // one long match: lanes stride over it; a period shorter than the length repeats
+                    const uint32_t ds = rdlane(val, k0);
+                    const uint8_t *src = gout + (d0 - ds);
+                    for (uint32_t j = lane; j < l0; j += 64) {
+                        uint32_t so = ds >= l0 ? j : small_mod(j, ds);
+                        uint8_t b = src[so];
+                        if (d0 + j < cap) gout[d0 + j] = b;
+                    }
+                    mm &= mm - 1;
+                    continue;
+                }
+                // longest run of matches from k0 that fits 64 bytes and reads nothing this step writes
+                uint64_t okm = __ballot(mlen && (mbi - b0 <= 64u) && (lane == k0 || srcend <= d0));
+                uint64_t rem = mm & ~okm;
+                uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
+                const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
+                const uint32_t nbytes = rdlane(mbi, lastl) - b0;
+                uint32_t mysrc = 0, mydst = 0;
+                for (uint64_t it = inc; it; it &= it - 1) {
+                    const uint32_t m = (uint32_t)__ffsll((long long)it) - 1;
+                    const uint32_t lo_ = rdlane(mbx, m) - b0, st = rdlane(start, m), ds = rdlane(val, m), ln = rdlane(mlen, m);
+                    if (lane >= lo_ && lane < lo_ + ln) {
+                        uint32_t off = lane - lo_;
+                        mydst = st + off;
+                        mysrc = st - ds + (ds >= ln ? off : small_mod(off, ds));
+                    }
+                }
+                if (lane < nbytes) {
+                    uint8_t b = gout[mysrc];
+                    if (mydst < cap) gout[mydst] = b;
+                }
+                mm &= ~inc;
             }
         }
         opos += total;
@@ -385,6 +440,172 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
         }
     }
     return true;
+}
+
+// ---- per-lane token decode (lanes are at different bit positions) ---------------------------------
+
+// total bits of the token starting at `pos` (pass 1: boundaries only).  End-of-block and invalid
+// codes count as their code length so that a lane decoding from a guessed start just keeps going.
+__device__ __forceinline__ uint32_t token_bits(const WaveLds &L, const InWin &w, uint32_t pos)
+{
+    uint32_t lo, hi;
+    win_bits(L, w, pos, lo, hi);
+    uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
+    if ((e & 15u) == 0) e = canon_lookup(L.lit_h, L.lit_sorted, __brev(lo) >> 17);
+    uint32_t n1 = (e & 15u) + ((e >> 4) & 15u);
+    if (((e >> 8) & 3u) == K_LEN) {
+        uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+        uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
+        if ((e2 & 15u) == 0) e2 = canon_lookup(L.dist_h, L.dist_sorted, __brev(w2) >> 17);
+        n1 += (e2 & 15u) + ((e2 >> 4) & 15u);
+    }
+    return n1;
+}
+
+enum : uint32_t { LS_NONE = 0, LS_EOB = 1, LS_NEED_INPUT = 2, LS_BAD = 3 };
+
+// Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them
+// into gout as it goes.  On return `pos` is behind the end-of-block code (status stays
+// ST_RUNNING) or status holds the reason decoding stopped.
+__device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
+                             const uint32_t cap, int32_t &status)
+{
+    const uint32_t lane = lane_id();
+    uint32_t *bm = L.tok;  // [word][lane] boundary bitmaps, dead before the tokens are written
+    for (;;) {
+        const uint32_t B = pos;
+        if (B >= end_bit) {
+            status = CHIP_NEED_INPUT;
+            return;
+        }
+        win_load(L, w, B >> 5);
+        const uint32_t s = B + lane * S_BITS;
+        uint32_t limit = s + S_BITS + O_BITS;
+        if (limit > end_bit) limit = end_bit;
+        // ---- pass 1: every lane walks token boundaries from its guessed start ------------------
+#pragma unroll
+        for (int k = 0; k < BM_WORDS; k++) bm[k * 64 + lane] = 0;
+        uint32_t p = s;
+        bool active = s < limit;
+        while (__any(active)) {
+            if (active) {
+                uint32_t rel = p - s;
+                atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
+                p += token_bits(L, w, p);
+                active = p < limit;
+            }
+        }
+        const uint32_t e_end = p;  // first boundary at or behind the lane's limit
+        WSYNC();
+        // ---- merge points: first boundary lane i shares with lane i-1 inside lane i's first O_BITS --
+        uint32_t m = 0xffffffffu;
+        if (lane == 0) m = B;
+        else if (s < end_bit) {
+#pragma unroll
+            for (int k = O_BITS / 32 - 1; k >= 0; k--) {
+                uint32_t c = bm[(S_BITS / 32 + k) * 64 + lane - 1] & bm[k * 64 + lane];
+                if (c) m = s + 32u * k + (uint32_t)__ffs((int)c) - 1;
+            }
+        }
+        const uint64_t failm = __ballot(m == 0xffffffffu);
+        uint32_t V = failm ? (uint32_t)__ffsll((long long)failm) - 1 : 64u;  // lanes 0..V-1 are on the true chain from m on
+        // lane i owns the tokens that start in [m_i, m_{i+1}); the last valid lane runs to its chain end
+        uint32_t up = (uint32_t)__shfl_down((int)m, 1, 64);
+        if (lane + 1 >= V) up = e_end;
+        uint32_t n = 0;
+        if (lane < V) {
+            const uint32_t lo_rel = m - s;
+            uint32_t hi_rel = up - s;
+            if (hi_rel > (uint32_t)(S_BITS + O_BITS)) hi_rel = S_BITS + O_BITS;
+#pragma unroll
+            for (int k = 0; k < BM_WORDS; k++) {
+                uint32_t word = bm[k * 64 + lane];
+                int lo_b = (int)lo_rel - 32 * k, hi_b = (int)hi_rel - 32 * k;
+                lo_b = lo_b < 0 ? 0 : (lo_b > 32 ? 32 : lo_b);
+                hi_b = hi_b < 0 ? 0 : (hi_b > 32 ? 32 : hi_b);
+                uint32_t below_hi = hi_b >= 32 ? 0xffffffffu : ((1u << hi_b) - 1u);
+                uint32_t below_lo = lo_b >= 32 ? 0xffffffffu : ((1u << lo_b) - 1u);
+                n += __popc(word & below_hi & ~below_lo);
+            }
+        }
+        uint32_t incl = wave_incl_scan(n);
+        uint32_t base = incl - n;
+        // keep the longest prefix of lanes whose tokens fit the buffer
+        const uint64_t fitm = __ballot(lane < V && incl <= (uint32_t)TOK_CAP);
+        const uint32_t V2 = (uint32_t)__popcll(fitm);
+        uint32_t next_B = V2 < V ? rdlane(m, V2 & 63u) : rdlane(e_end, (V - 1) & 63u);
+        if (V2 < V) {
+            if (lane + 1 == V2) up = next_B;
+            V = V2;
+        }
+        WSYNC();
+        // ---- pass 2: exact decode of the owned ranges, tokens written in stream order --------------
+        uint32_t k = 0, lstat = LS_NONE, stop_pos = 0;
+        p = m;
+        active = lane < V && n > 0;
+        while (__any(active)) {
+            if (active) {
+                uint32_t lo, hi;
+                win_bits(L, w, p, lo, hi);
+                uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
+                if ((e & 15u) == 0) e = canon_lookup(L.lit_h, L.lit_sorted, __brev(lo) >> 17);
+                const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+                uint32_t n1 = cl + eb;
+                uint32_t token = tok_lit(e >> 16);
+                uint32_t st = LS_NONE;
+                if (kind == K_LEN) {
+                    uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+                    uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
+                    if ((e2 & 15u) == 0) e2 = canon_lookup(L.dist_h, L.dist_sorted, __brev(w2) >> 17);
+                    const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
+                    token = tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2));
+                    if (p + n1 + cl2 + eb2 > end_bit) st = LS_NEED_INPUT;
+                    else if (((e2 >> 8) & 3u) == K_BAD) st = LS_BAD;
+                    n1 += cl2 + eb2;
+                } else if (p + n1 > end_bit) st = LS_NEED_INPUT;
+                else if (kind == K_EOB) st = LS_EOB;
+                else if (kind == K_BAD) st = LS_BAD;
+                if (st != LS_NONE) {
+                    lstat = st;
+                    stop_pos = p + cl;  // behind the end-of-block code
+                    active = false;
+                } else {
+                    L.tok[base + k] = token;
+                    k++;
+                    p += n1;
+                    active = k < n;
+                }
+            }
+        }
+        WSYNC();
+        const uint64_t stopm = __ballot(lstat != LS_NONE);
+        uint32_t T = rdlane(incl, (V - 1) & 63u);
+        uint32_t first_stat = LS_NONE, first_stop = 0;
+        if (stopm) {
+            const uint32_t E = (uint32_t)__ffsll((long long)stopm) - 1;
+            T = rdlane(base + k, E);
+            first_stat = rdlane(lstat, E);
+            first_stop = rdlane(stop_pos, E);
+        }
+        int32_t st2 = ST_RUNNING;
+        if (!flush_tokens(L, T, gout, opos, cap, st2)) {
+            status = st2;
+            return;
+        }
+        if (first_stat == LS_EOB) {
+            pos = first_stop;
+            return;
+        }
+        if (first_stat == LS_NEED_INPUT) {
+            status = CHIP_NEED_INPUT;
+            return;
+        }
+        if (first_stat == LS_BAD) {
+            status = Z_DATA_ERROR;
+            return;
+        }
+        pos = next_B;
+    }
 }
 
 __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
@@ -409,7 +630,6 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
 
     uint32_t pos = start_bit;
     uint32_t opos = 0;
-    uint32_t ntok = 0;
     int32_t status = ST_RUNNING;
     bool last = false;
     int tables = 0;  // 0 none, 1 fixed, 2 dynamic
@@ -569,65 +789,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                 break;
             }
         }
-        // ---- token loop --------------------------------------------------------------------
-        for (;;) {
-            win_ensure(L, w, pos);
-            win_bits(L, w, pos, lo, hi);
-            uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-            if ((e & 15u) == 0) e = canon_lookup(L.lit_h, L.lit_sorted, __brev(lo) >> 17);
-            uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
-            uint32_t n1 = cl + eb;
-            if (pos + n1 > end_bit) {
-                status = CHIP_NEED_INPUT;
-                break;
-            }
-            if (kind == K_LIT) {
-                if (lane == 0) L.tok[ntok] = tok_lit(e >> 16);
-                pos += cl;
-            } else if (kind == K_EOB) {
-                pos += cl;
-                break;
-            } else if (kind == K_BAD) {
-                status = Z_DATA_ERROR;
-                break;
-            } else {
-                uint32_t len = (e >> 16) + bfe(lo, cl, eb);
-                uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-                uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-                if ((e2 & 15u) == 0) e2 = canon_lookup(L.dist_h, L.dist_sorted, __brev(w2) >> 17);
-                uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-                uint32_t n2 = cl2 + eb2;
-                if (pos + n1 + n2 > end_bit) {
-                    status = CHIP_NEED_INPUT;
-                    break;
-                }
-                if (((e2 >> 8) & 3u) == K_BAD) {
-                    status = Z_DATA_ERROR;
-                    break;
-                }
-                uint32_t dist = (e2 >> 16) + bfe(w2, cl2, eb2);
-                if (lane == 0) L.tok[ntok] = tok_match(len, dist);
-                pos += n1 + n2;
-            }
-            ntok++;
-            if (ntok == TOK_CAP) {
-                WSYNC();
-                int32_t st2 = ST_RUNNING;
-                bool ok = flush_tokens(L, ntok, gout, opos, cap, st2);
-                ntok = 0;
-                WSYNC();
-                if (!ok) {
-                    status = st2;
-                    break;
-                }
-            }
-        }
-    }
-    // tokens decoded before a stop condition are still output (zlib writes everything it decoded)
-    if (ntok) {
-        WSYNC();
-        int32_t st2 = ST_RUNNING;
-        if (!flush_tokens(L, ntok, gout, opos, cap, st2)) status = st2;
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status);
     }
     if (status == CHIP_FINISHED && wrap) {
         // trailer: gzip CRC-32 + ISIZE (little endian), zlib Adler-32 (big endian)
