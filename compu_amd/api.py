@@ -14,7 +14,8 @@ _LIB_NAME = "libcompu_hip.so"
 
 
 def lib_path():
-    return os.path.join(_HERE, _LIB_NAME)
+    # COMPU_HIP_LIB selects another build of the same library (diagnostic builds); never a CPU stand-in
+    return os.environ.get("COMPU_HIP_LIB") or os.path.join(_HERE, _LIB_NAME)
 
 
 class _DecodeResult(C.Structure):

@@ -120,6 +120,10 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     a.status = status;
     a.n = (uint32_t)n;
     a.format = format;
+    a.stats = nullptr;
+#ifdef CHIP_STATS
+    a.stats = (unsigned long long *)getenv("CHIP_STATS_PTR") ? (unsigned long long *)strtoull(getenv("CHIP_STATS_PTR"), nullptr, 0) : nullptr;
+#endif
     hipError_t e;
     switch (format) {
     case CHIP_FMT_DEFLATE:
@@ -275,6 +279,7 @@ bool dec_run(chip_decoder *d)
         a.status = &d->d_meta->status;
         a.n = 1;
         a.format = d->format;
+        a.stats = nullptr;
         hipError_t e = d->format == CHIP_FMT_ZSTD ? launch_zstd_decode(a, d->window_log_max, d->stream) : launch_inflate(a, d->stream);
         if (e != hipSuccess) return false;
         if (hipMemcpyAsync(d->h_meta, d->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;

@@ -7,3 +7,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
     -o "$out" "$here"/*.hip "$@"
 echo "built $out"
+if [ "${CHIP_BUILD_STATS:-0}" = "1" ]; then
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -DCHIP_STATS \
+        -o "$here/../libcompu_hip_stats.so" "$here"/*.hip
+    echo "built $here/../libcompu_hip_stats.so (diagnostic)"
+fi

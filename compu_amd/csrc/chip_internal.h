@@ -36,6 +36,7 @@ struct BatchArgs {
     int32_t *status;
     uint32_t n;
     int32_t format;
+    unsigned long long *stats;  // diagnostic builds only (-DCHIP_STATS): 16 words per unit, else nullptr
 };
 
 // launchers (each only enqueues on `stream`)
@@ -73,6 +74,22 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
     v += dpp_or_zero<0x143, 0xc>(v);
     return v;
 }
+
+// inclusive running maximum across the wave (same DPP ladder; 0 is the identity for unsigned max)
+__device__ __forceinline__ uint32_t wave_incl_max_scan(uint32_t v)
+{
+    uint32_t t;
+    t = dpp_or_zero<0x111>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x112>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x114>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x118>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x142, 0xa>(v); v = v > t ? v : t;
+    t = dpp_or_zero<0x143, 0xc>(v); v = v > t ? v : t;
+    return v;
+}
+
+// value of the previous lane (lane 0 gets 0): DPP wave_shr:1
+__device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp_or_zero<0x138>(v); }
 
 // LDS written by some lanes of the (single) wave, read by others: order + visibility
 #define WSYNC() __syncthreads()

@@ -14,6 +14,26 @@
 
 namespace chip {
 
+// Diagnostic build (-DCHIP_STATS): per-unit cycle and event counters; compiled out of the product.
+#ifdef CHIP_STATS
+#define STAT_DECL unsigned long long st_[16] = {0}; unsigned long long st_t0_ = 0
+#define STAT_T0() (st_t0_ = __builtin_readcyclecounter())
+#define STAT_ACC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); st_[i] += n_ - st_t0_; st_t0_ = n_; } while (0)
+#define STAT_ADD(i, v) (st_[i] += (unsigned long long)(v))
+struct Stats { unsigned long long *st_; unsigned long long &st_t0_; };
+#define STAT_PARAM , unsigned long long *st_, unsigned long long &st_t0_
+#define STAT_ARG , st_, st_t0_
+#else
+#define STAT_DECL
+#define STAT_T0()
+#define STAT_ACC(i)
+#define STAT_ADD(i, v)
+#define STAT_PARAM
+#define STAT_ARG
+#endif
+// stat slots: 0 header+tables, 1 window load, 2 pass1, 3 resolve, 4 pass2, 5 flush, 6 checksum/trailer,
+// 8 super-rounds, 9 sum of valid lanes, 10 tokens, 11 pass1 iterations, 12 pass2 iterations, 13 flush groups, 14 match steps, 15 fix-up rounds
+
 // ---- table entry format (shared by lit/len, distance and code-length tables) -------------------
 // [3:0] code length (0 = longer than the root table, resolve canonically)
 // [7:4] number of extra bits, [9:8] kind, [31:16] base value
@@ -31,12 +51,19 @@ constexpr int CL_ROOT = 7;
 // starting at B + i*S_BITS and decodes O_BITS further into its successor's range so that the point
 // where the two decodes fall into step (the merge) can be proven.  S_BITS is an odd number of
 // dwords so that the 64 lanes' window reads hit distinct LDS banks.
-constexpr int S_BITS = 288;
-constexpr int O_BITS = 256;
+#ifndef CHIP_S_BITS
+#define CHIP_S_BITS 288
+#define CHIP_O_BITS 256
+#define CHIP_TOK_CAP 2304
+#define CHIP_FIX_ROUNDS 3
+#endif
+constexpr int S_BITS = CHIP_S_BITS;
+constexpr int O_BITS = CHIP_O_BITS;
 static_assert(O_BITS <= S_BITS && S_BITS % 32 == 0 && O_BITS % 32 == 0, "geometry");
 constexpr int BM_WORDS = (S_BITS + O_BITS) / 32;  // boundary bitmap words per lane
-constexpr int IN_DW = 592;     // staged input window, dwords: 64*S_BITS + O_BITS + one token + slack
-constexpr int TOK_CAP = 2304;  // token buffer capacity (also holds the boundary bitmaps during pass 1)
+constexpr int IN_DW = (31 + 64 * S_BITS + O_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
+constexpr int FIX_ROUNDS = CHIP_FIX_ROUNDS;  // restarts of lanes that did not merge, per super-round
+constexpr int TOK_CAP = CHIP_TOK_CAP;  // token buffer capacity (also holds the boundary bitmaps during pass 1)
 static_assert(BM_WORDS * 64 <= TOK_CAP, "bitmaps alias the token buffer");
 static_assert(IN_DW * 32 >= 31 + 63 * S_BITS + S_BITS + O_BITS + 48 + 96, "window covers every lane's reads");
 
@@ -56,7 +83,7 @@ struct alignas(16) WaveLds {
     uint32_t lit_sorted[288];
     uint32_t dist_sorted[32];
     uint32_t inbuf[IN_DW];
-    uint32_t tok[TOK_CAP];
+    uint32_t tok[TOK_CAP + 192];  // tokens (and pass-1 bitmaps), then 192 words of copy-phase scratch
     uint32_t cl_lut[1 << CL_ROOT];
     uint32_t cl_sorted[20];
     HuffMeta lit_h, dist_h, cl_h;
@@ -92,6 +119,43 @@ __device__ __forceinline__ uint32_t canon_lookup(const HuffMeta &H, const uint32
 #pragma unroll
     for (int j = 1; j < 15; j++) l += (x15 >= H.limit15[j]) ? 1u : 0u;
     return sorted[H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l))];
+}
+
+// Codes longer than the root table are resolved canonically from wave-uniform registers (no LDS
+// traffic besides the final sorted[] read).  q[j] describes length l = ROOT+1+j:
+//   [15:0] limit15[l-1] (start of the length-l code space), [24:16] offs[l], [28:25] 15-l
+template <int ROOT>
+struct LongCodes {
+    uint32_t q[15 - ROOT];
+    uint32_t top;  // limit15[15]: code space at and above it is unused (incomplete set)
+    uint32_t bad;  // entry returned for unused code space
+};
+
+template <int ROOT>
+__device__ __forceinline__ LongCodes<ROOT> load_long_codes(const HuffMeta &H)
+{
+    LongCodes<ROOT> lc;
+#pragma unroll
+    for (int j = 0; j < 15 - ROOT; j++) {
+        const int l = ROOT + 1 + j;
+        lc.q[j] = rdfirst(H.limit15[l - 1] | (H.offs[l] << 16) | ((uint32_t)(15 - l) << 25));
+    }
+    lc.top = rdfirst(H.limit15[15]);
+    uint32_t ml = rdfirst(H.maxlen);
+    lc.bad = mk_entry(ml ? ml : 1u, 0, K_BAD, 0);
+    return lc;
+}
+
+template <int ROOT>
+__device__ __forceinline__ uint32_t long_lookup(const LongCodes<ROOT> &lc, const uint32_t *sorted, uint32_t x15)
+{
+    uint32_t q = lc.q[0];
+#pragma unroll
+    for (int j = 1; j < 15 - ROOT; j++)
+        if (x15 >= (lc.q[j] & 0xffffu)) q = lc.q[j];
+    uint32_t k = ((q >> 16) & 0x1ffu) + ((x15 - (q & 0xffffu)) >> (q >> 25));
+    uint32_t e = sorted[k < 288u ? k : 0u];
+    return x15 >= lc.top ? lc.bad : e;
 }
 
 // Build a canonical Huffman decode table from code lengths (RFC 1951 sec. 3.2.2) with zlib's
@@ -356,10 +420,11 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 // are scattered with one byte store per 64 tokens; matches are copied several at a time, one
 // output byte per lane, as long as no source range reaches into bytes the same step writes.
 // Returns false when decoding must stop (error / output full).
-__device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status)
+__device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     for (uint32_t g = 0; g < ntok; g += 64) {
+        STAT_ADD(13, 1);
         uint32_t i = g + lane;
         bool valid = i < ntok;
         uint32_t t = valid ? L.tok[i] : 0u;
@@ -389,12 +454,15 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
             uint32_t mbi = wave_incl_scan(mlen);  // match bytes up to and including this match
             uint32_t mbx = mbi - mlen;
             uint32_t srcend = start - val + (len < val ? len : val);  // end of the bytes actually read
+            uint32_t *const fl_heads = &L.tok[TOK_CAP];        // 64 words: owner rank+1 per match byte of a step
+            uint32_t *const fl_par = &L.tok[TOK_CAP + 64];     // 64 x 2 words: per-match parameters by rank
             while (mm) {
+                STAT_ADD(14, 1);
                 const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
                 const uint32_t d0 = rdlane(start, k0), b0 = rdlane(mbx, k0), l0 = rdlane(mlen, k0);
                 if (d0 >= cap) break;  // everything from here on lies behind the output capacity
-                if (l0 > 64) {
-                    // one long match: lanes stride over it; a period shorter than the length repeats
+                if (l0 > 256) {
+                    // a single very long match: lanes stride over it; a period shorter than the length repeats
                     const uint32_t ds = rdlane(val, k0);
                     const uint8_t *src = gout + (d0 - ds);
                     for (uint32_t j = lane; j < l0; j += 64) {
@@ -405,26 +473,53 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
                     mm &= mm - 1;
                     continue;
                 }
-                // longest run of matches from k0 that fits 64 bytes and reads nothing this step writes
-                uint64_t okm = __ballot(mlen && (mbi - b0 <= 64u) && (lane == k0 || srcend <= d0));
-                uint64_t rem = mm & ~okm;
-                uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
+                // longest run of matches from k0 that fits 256 bytes and reads nothing this step writes
+                const uint64_t okm = __ballot(mlen && (mbi - b0 <= 256u) && (lane == k0 || srcend <= d0));
+                const uint64_t rem = mm & ~okm;
+                const uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
                 const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
                 const uint32_t nbytes = rdlane(mbi, lastl) - b0;
-                uint32_t mysrc = 0, mydst = 0;
-                for (uint64_t it = inc; it; it &= it - 1) {
-                    const uint32_t m = (uint32_t)__ffsll((long long)it) - 1;
-                    const uint32_t lo_ = rdlane(mbx, m) - b0, st = rdlane(start, m), ds = rdlane(val, m), ln = rdlane(mlen, m);
-                    if (lane >= lo_ && lane < lo_ + ln) {
-                        uint32_t off = lane - lo_;
-                        mydst = st + off;
-                        mysrc = st - ds + (ds >= ln ? off : small_mod(off, ds));
-                    }
+                // owner of every match byte: heads scattered by rank, then a running maximum
+                fl_heads[lane] = 0;
+                const bool mine = (inc >> lane) & 1ull;
+                if (mine) {
+                    const uint32_t rank = (uint32_t)__popcll(inc & lanemask_lt());
+                    const uint32_t rel = mbx - b0;
+                    ((uint8_t *)fl_heads)[rel] = (uint8_t)(rank + 1);
+                    fl_par[2 * rank] = start;
+                    fl_par[2 * rank + 1] = val | ((mlen - 1u) << 16) | (rel << 24);
                 }
-                if (lane < nbytes) {
-                    uint8_t b = gout[mysrc];
-                    if (mydst < cap) gout[mydst] = b;
+                WSYNC();  // other lanes' scatter must be visible (and not forwarded past) before the reads
+                const uint32_t h = fl_heads[lane];
+                uint32_t r0 = h & 0xffu, r1 = (h >> 8) & 0xffu, r2 = (h >> 16) & 0xffu, r3 = h >> 24;
+                r1 = r1 > r0 ? r1 : r0;
+                r2 = r2 > r1 ? r2 : r1;
+                r3 = r3 > r2 ? r3 : r2;
+                const uint32_t carry = wave_shr1(wave_incl_max_scan(r3));
+                r0 = r0 > carry ? r0 : carry;
+                r1 = r1 > carry ? r1 : carry;
+                r2 = r2 > carry ? r2 : carry;
+                r3 = r3 > carry ? r3 : carry;
+                const uint32_t rr[4] = {r0, r1, r2, r3};
+                uint32_t srcs[4], dsts[4];
+                bool has[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t q = 4u * lane + j;
+                    has[j] = q < nbytes;
+                    const uint32_t r = (has[j] && rr[j]) ? rr[j] - 1u : 0u;
+                    const uint32_t st = fl_par[2 * r], pv = fl_par[2 * r + 1];
+                    const uint32_t ds = pv & 0xffffu, ln = ((pv >> 16) & 0xffu) + 1u, off = q - (pv >> 24);
+                    dsts[j] = st + off;
+                    srcs[j] = st - ds + (ds >= ln ? off : small_mod(off, ds));
                 }
+                WSYNC();  // every lane has read the scratch before the next step rewrites it
+                uint8_t bytes[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bytes[j] = has[j] ? gout[srcs[j]] : (uint8_t)0;
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (has[j] && dsts[j] < cap) gout[dsts[j]] = bytes[j];
                 mm &= ~inc;
             }
         }
@@ -446,17 +541,18 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
 
 // total bits of the token starting at `pos` (pass 1: boundaries only).  End-of-block and invalid
 // codes count as their code length so that a lane decoding from a guessed start just keeps going.
-__device__ __forceinline__ uint32_t token_bits(const WaveLds &L, const InWin &w, uint32_t pos)
+__device__ __forceinline__ uint32_t token_bits(const WaveLds &L, const InWin &w, uint32_t pos, const LongCodes<LIT_ROOT> &lcl,
+                                               const LongCodes<DIST_ROOT> &lcd)
 {
     uint32_t lo, hi;
     win_bits(L, w, pos, lo, hi);
     uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-    if ((e & 15u) == 0) e = canon_lookup(L.lit_h, L.lit_sorted, __brev(lo) >> 17);
+    if ((e & 15u) == 0) e = long_lookup<LIT_ROOT>(lcl, L.lit_sorted, __brev(lo) >> 17);
     uint32_t n1 = (e & 15u) + ((e >> 4) & 15u);
     if (((e >> 8) & 3u) == K_LEN) {
         uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
         uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-        if ((e2 & 15u) == 0) e2 = canon_lookup(L.dist_h, L.dist_sorted, __brev(w2) >> 17);
+        if ((e2 & 15u) == 0) e2 = long_lookup<DIST_ROOT>(lcd, L.dist_sorted, __brev(w2) >> 17);
         n1 += (e2 & 15u) + ((e2 >> 4) & 15u);
     }
     return n1;
@@ -468,9 +564,11 @@ enum : uint32_t { LS_NONE = 0, LS_EOB = 1, LS_NEED_INPUT = 2, LS_BAD = 3 };
 // into gout as it goes.  On return `pos` is behind the end-of-block code (status stays
 // ST_RUNNING) or status holds the reason decoding stopped.
 __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                             const uint32_t cap, int32_t &status)
+                             const uint32_t cap, int32_t &status STAT_PARAM)
 {
     const uint32_t lane = lane_id();
+    const LongCodes<LIT_ROOT> lcl = load_long_codes<LIT_ROOT>(L.lit_h);
+    const LongCodes<DIST_ROOT> lcd = load_long_codes<DIST_ROOT>(L.dist_h);
     uint32_t *bm = L.tok;  // [word][lane] boundary bitmaps, dead before the tokens are written
     for (;;) {
         const uint32_t B = pos;
@@ -478,7 +576,10 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
             status = CHIP_NEED_INPUT;
             return;
         }
+        STAT_T0();
         win_load(L, w, B >> 5);
+        STAT_ACC(1);
+        STAT_ADD(8, 1);
         const uint32_t s = B + lane * S_BITS;
         uint32_t limit = s + S_BITS + O_BITS;
         if (limit > end_bit) limit = end_bit;
@@ -488,25 +589,60 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         uint32_t p = s;
         bool active = s < limit;
         while (__any(active)) {
+            STAT_ADD(11, 1);
             if (active) {
                 uint32_t rel = p - s;
                 atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-                p += token_bits(L, w, p);
+                p += token_bits(L, w, p, lcl, lcd);
                 active = p < limit;
             }
         }
-        const uint32_t e_end = p;  // first boundary at or behind the lane's limit
+        uint32_t e_end = p;  // first boundary at or behind the lane's limit
         WSYNC();
+        STAT_ACC(2);
         // ---- merge points: first boundary lane i shares with lane i-1 inside lane i's first O_BITS --
-        uint32_t m = 0xffffffffu;
-        if (lane == 0) m = B;
-        else if (s < end_bit) {
+        auto merge_point = [&]() -> uint32_t {
+            uint32_t r = 0xffffffffu;
 #pragma unroll
             for (int k = O_BITS / 32 - 1; k >= 0; k--) {
                 uint32_t c = bm[(S_BITS / 32 + k) * 64 + lane - 1] & bm[k * 64 + lane];
-                if (c) m = s + 32u * k + (uint32_t)__ffs((int)c) - 1;
+                if (c) r = s + 32u * k + (uint32_t)__ffs((int)c) - 1;
             }
+            return r;
+        };
+        uint32_t m = 0xffffffffu;
+        if (lane == 0) m = B;
+        else if (s < end_bit) m = merge_point();
+        // ---- fix-up rounds: a lane that did not fall into step with its predecessor starts over at
+        // the predecessor's last boundary (consistent by construction); pairs next to a redone lane
+        // are checked again.  Consecutive misses resolve one per round.
+        for (int round = 0; round < FIX_ROUNDS; round++) {
+            const uint32_t prev_end = (uint32_t)__shfl_up((int)e_end, 1, 64);
+            const bool redo = lane > 0 && m == 0xffffffffu && prev_end < limit;
+            if (!__any(redo)) break;
+            STAT_ADD(15, 1);
+            if (redo) {
+#pragma unroll
+                for (int k = 0; k < BM_WORDS; k++) bm[k * 64 + lane] = 0;
+                p = prev_end;
+                m = prev_end;
+            }
+            active = redo;
+            while (__any(active)) {
+                STAT_ADD(11, 1);
+                if (active) {
+                    uint32_t rel = p - s;
+                    atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
+                    p += token_bits(L, w, p, lcl, lcd);
+                    active = p < limit;
+                }
+            }
+            if (redo) e_end = p;
+            WSYNC();
+            const bool pred_redo = __shfl_up((int)redo, 1, 64) != 0;
+            if (lane > 0 && pred_redo && s < end_bit) m = merge_point();
         }
+        STAT_ACC(3);
         const uint64_t failm = __ballot(m == 0xffffffffu);
         uint32_t V = failm ? (uint32_t)__ffsll((long long)failm) - 1 : 64u;  // lanes 0..V-1 are on the true chain from m on
         // lane i owns the tokens that start in [m_i, m_{i+1}); the last valid lane runs to its chain end
@@ -539,16 +675,18 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
             V = V2;
         }
         WSYNC();
+        STAT_ADD(9, V);
         // ---- pass 2: exact decode of the owned ranges, tokens written in stream order --------------
         uint32_t k = 0, lstat = LS_NONE, stop_pos = 0;
         p = m;
         active = lane < V && n > 0;
         while (__any(active)) {
+            STAT_ADD(12, 1);
             if (active) {
                 uint32_t lo, hi;
                 win_bits(L, w, p, lo, hi);
                 uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-                if ((e & 15u) == 0) e = canon_lookup(L.lit_h, L.lit_sorted, __brev(lo) >> 17);
+                if ((e & 15u) == 0) e = long_lookup<LIT_ROOT>(lcl, L.lit_sorted, __brev(lo) >> 17);
                 const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
                 uint32_t n1 = cl + eb;
                 uint32_t token = tok_lit(e >> 16);
@@ -556,7 +694,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
                 if (kind == K_LEN) {
                     uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
                     uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-                    if ((e2 & 15u) == 0) e2 = canon_lookup(L.dist_h, L.dist_sorted, __brev(w2) >> 17);
+                    if ((e2 & 15u) == 0) e2 = long_lookup<DIST_ROOT>(lcd, L.dist_sorted, __brev(w2) >> 17);
                     const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
                     token = tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2));
                     if (p + n1 + cl2 + eb2 > end_bit) st = LS_NEED_INPUT;
@@ -587,8 +725,12 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
             first_stat = rdlane(lstat, E);
             first_stop = rdlane(stop_pos, E);
         }
+        STAT_ACC(4);
+        STAT_ADD(10, T);
         int32_t st2 = ST_RUNNING;
-        if (!flush_tokens(L, T, gout, opos, cap, st2)) {
+        bool flushed = flush_tokens(L, T, gout, opos, cap, st2 STAT_ARG);
+        STAT_ACC(5);
+        if (!flushed) {
             status = st2;
             return;
         }
@@ -634,6 +776,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
     bool last = false;
     int tables = 0;  // 0 none, 1 fixed, 2 dynamic
 
+    STAT_DECL;
+    STAT_T0();
     uint32_t wrap = 0;
     if (a.format != CHIP_FMT_DEFLATE) {
         uint32_t hdr = 0;
@@ -789,8 +933,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                 break;
             }
         }
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status);
+        STAT_ACC(0);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status STAT_ARG);
+        STAT_T0();
     }
+    STAT_ACC(0);
     if (status == CHIP_FINISHED && wrap) {
         // trailer: gzip CRC-32 + ISIZE (little endian), zlib Adler-32 (big endian)
         uint32_t k = (pos - start_bit + 7u) >> 3;
@@ -815,6 +962,11 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
         }
         pos = start_bit + k * 8u;
     }
+    STAT_ACC(6);
+#ifdef CHIP_STATS
+    if (a.stats && lane == 0)
+        for (int k = 0; k < 16; k++) a.stats[(size_t)u * 16 + k] = st_[k];
+#endif
     if (lane == 0) {
         uint32_t used = (pos - start_bit + 7u) >> 3;
         if (used > in_len) used = in_len;
