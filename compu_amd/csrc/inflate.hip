@@ -16,7 +16,7 @@ namespace chip {
 
 // Diagnostic build (-DCHIP_STATS): per-unit cycle and event counters; compiled out of the product.
 #ifdef CHIP_STATS
-#define STAT_DECL unsigned long long st_[16] = {0}; unsigned long long st_t0_ = 0
+#define STAT_DECL unsigned long long st_[24] = {0}; unsigned long long st_t0_ = 0
 #define STAT_T0() (st_t0_ = __builtin_readcyclecounter())
 #define STAT_ACC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); st_[i] += n_ - st_t0_; st_t0_ = n_; } while (0)
 #define STAT_ADD(i, v) (st_[i] += (unsigned long long)(v))
@@ -409,11 +409,65 @@ __device__ int32_t parse_wrapper(uint32_t *tab, const uint8_t *gin, uint32_t ava
     return ST_RUNNING;
 }
 
+// Stored-block payload: copy n bytes from byte offset `so` of the unit's dword-aligned input view
+// to gdst.  Byte copies bring the destination to 16-byte alignment, then every lane moves 16 bytes
+// per trip: dwordx4 + dword loads from the (at most 4-byte aligned) source, a funnel shift by the
+// source's byte misalignment, one aligned dwordx4 store -- a structured memcpy at HBM rate.
+__device__ void wave_copy_stored(uint8_t *gdst, const uint32_t *g32, uint32_t total_dw, uint32_t so, uint32_t n)
+{
+    const uint32_t lane = lane_id();
+    const uint8_t *gsrc = (const uint8_t *)g32 + so;
+    uint32_t head = (uint32_t)((16u - ((uintptr_t)gdst & 15u)) & 15u);
+    if (head > n) head = n;
+    if (lane < head) gdst[lane] = gsrc[lane];
+    uint32_t done = head;
+    const uint32_t body = (n - done) & ~15u;
+    if (body) {
+        const uint32_t sb = so + done;          // source byte offset of the body
+        const uint32_t sd = sb >> 2, sh = (sb & 3u) * 8u;
+        uint4 *d16 = (uint4 *)(gdst + done);
+        for (uint32_t i = lane; i < (body >> 4); i += 64) {
+            const uint32_t w0 = sd + 4u * i;
+            uint32_t a0 = g32[w0], a1 = g32[w0 + 1], a2 = g32[w0 + 2], a3 = g32[w0 + 3];
+            uint32_t a4 = (sh && w0 + 4 < total_dw) ? g32[w0 + 4] : 0u;
+            uint4 o;
+            o.x = __builtin_amdgcn_alignbit(a1, a0, sh);
+            o.y = __builtin_amdgcn_alignbit(a2, a1, sh);
+            o.z = __builtin_amdgcn_alignbit(a3, a2, sh);
+            o.w = __builtin_amdgcn_alignbit(a4, a3, sh);
+            d16[i] = o;
+        }
+        done += body;
+    }
+    const uint32_t tail = n - done;
+    if (lane < tail) gdst[done + lane] = gsrc[done + lane];
+}
+
 // (off % d) for off, d < 512 without an integer divide
 __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 {
     uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)d));
     return off - q * d;
+}
+
+// One copy step whose loads are in flight: its stores are issued only when the next step's loads
+// have been issued too (or when the next step reads what this one writes).
+struct PendingCopy {
+    uint32_t dst[4];
+    uint8_t byte[4];
+    bool has[4];
+    bool valid;
+    uint32_t d0;  // lowest destination of the step
+};
+
+__device__ __forceinline__ void drain_copy(PendingCopy &pc, uint8_t *gout, uint32_t cap)
+{
+    if (pc.valid) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (pc.has[j] && pc.dst[j] < cap) gout[pc.dst[j]] = pc.byte[j];
+        pc.valid = false;
+    }
 }
 
 // LZ77 execution of tok[0..ntok): wave prefix sums give every token its output position; literals
@@ -423,6 +477,15 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status STAT_PARAM)
 {
     const uint32_t lane = lane_id();
+    PendingCopy pc;
+    pc.valid = false;
+    pc.d0 = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        pc.dst[j] = 0;
+        pc.byte[j] = 0;
+        pc.has[j] = false;
+    }
     for (uint32_t g = 0; g < ntok; g += 64) {
         STAT_ADD(13, 1);
         uint32_t i = g + lane;
@@ -450,6 +513,7 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
         if (valid && !len && start < cap) gout[start] = (uint8_t)val;
         uint32_t mlen = (valid && len) ? len : 0u;
         uint64_t mm = __ballot(mlen != 0);
+        STAT_ACC(16);
         if (mm) {
             uint32_t mbi = wave_incl_scan(mlen);  // match bytes up to and including this match
             uint32_t mbx = mbi - mlen;
@@ -462,6 +526,7 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
                 const uint32_t d0 = rdlane(start, k0), b0 = rdlane(mbx, k0), l0 = rdlane(mlen, k0);
                 if (d0 >= cap) break;  // everything from here on lies behind the output capacity
                 if (l0 > 256) {
+                    drain_copy(pc, gout, cap);
                     // a single very long match: lanes stride over it; a period shorter than the length repeats
                     const uint32_t ds = rdlane(val, k0);
                     const uint8_t *src = gout + (d0 - ds);
@@ -479,6 +544,7 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
                 const uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
                 const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
                 const uint32_t nbytes = rdlane(mbi, lastl) - b0;
+                STAT_ACC(17);
                 // owner of every match byte: heads scattered by rank, then a running maximum
                 fl_heads[lane] = 0;
                 const bool mine = (inc >> lane) & 1ull;
@@ -514,26 +580,40 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
                     srcs[j] = st - ds + (ds >= ln ? off : small_mod(off, ds));
                 }
                 WSYNC();  // every lane has read the scratch before the next step rewrites it
+                STAT_ACC(18);
+                // software pipeline: this step's loads go out before the previous step's stores unless
+                // this step reads bytes the previous one writes
+                if (pc.valid && __any(mine && srcend > pc.d0)) drain_copy(pc, gout, cap);
                 uint8_t bytes[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) bytes[j] = has[j] ? gout[srcs[j]] : (uint8_t)0;
+                for (int j = 0; j < 4; j++) bytes[j] = gout[has[j] ? srcs[j] : 0u];  // lanes without a byte re-read byte 0
+                drain_copy(pc, gout, cap);
 #pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if (has[j] && dsts[j] < cap) gout[dsts[j]] = bytes[j];
+                for (int j = 0; j < 4; j++) {
+                    pc.dst[j] = dsts[j];
+                    pc.byte[j] = bytes[j];
+                    pc.has[j] = has[j];
+                }
+                pc.valid = true;
+                pc.d0 = d0;
                 mm &= ~inc;
+                STAT_ACC(19);
             }
         }
         opos += total;
         if (opos > cap) {
+            drain_copy(pc, gout, cap);
             opos = cap;
             status = CHIP_NEED_OUTPUT;
             return false;
         }
         if (err) {
+            drain_copy(pc, gout, cap);
             status = err;
             return false;
         }
     }
+    drain_copy(pc, gout, cap);
     return true;
 }
 
@@ -729,7 +809,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         STAT_ADD(10, T);
         int32_t st2 = ST_RUNNING;
         bool flushed = flush_tokens(L, T, gout, opos, cap, st2 STAT_ARG);
-        STAT_ACC(5);
+        STAT_ACC(20);
         if (!flushed) {
             status = st2;
             return;
@@ -820,8 +900,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
             uint32_t room = cap - opos;
             uint32_t ncopy = blen < avail ? blen : avail;
             if (ncopy > room) ncopy = room;
-            const uint8_t *src = gin + ((pos - start_bit) >> 3);
-            for (uint32_t j = lane; j < ncopy; j += 64) gout[opos + j] = src[j];
+            wave_copy_stored(gout + opos, w.g32, w.total_dw, pos >> 3, ncopy);
             opos += ncopy;
             pos += ncopy * 8u;
             if (ncopy < blen) {
@@ -965,7 +1044,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
     STAT_ACC(6);
 #ifdef CHIP_STATS
     if (a.stats && lane == 0)
-        for (int k = 0; k < 16; k++) a.stats[(size_t)u * 16 + k] = st_[k];
+        for (int k = 0; k < 24; k++) a.stats[(size_t)u * 24 + k] = st_[k];
 #endif
     if (lane == 0) {
         uint32_t used = (pos - start_bit + 7u) >> 3;

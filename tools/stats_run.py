@@ -18,7 +18,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 dev = torch.device("cuda:0")
 pay = synth.payloads(n)
 packed, offs, lens = synth.deflate_units(pay, n, kind=kind)
-stats = torch.zeros(n * 16, dtype=torch.int64, device=dev)
+stats = torch.zeros(n * 24, dtype=torch.int64, device=dev)
 os.environ["CHIP_STATS_PTR"] = str(stats.data_ptr())
 d_out = torch.zeros(n * 65536, dtype=torch.uint8, device=dev)
 args = (-15, torch.from_numpy(packed).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev),
@@ -32,15 +32,15 @@ compu_amd.decode_batch(*args)
 b.record()
 torch.cuda.synchronize()
 assert (st == 2).all() and torch.equal(d_out, torch.from_numpy(pay).to(dev))
-s = stats.cpu().numpy().reshape(n, 16).astype(np.float64)
+s = stats.cpu().numpy().reshape(n, 24).astype(np.float64)
 names = ["hdr+tables", "win_load", "pass1", "resolve", "pass2", "flush", "trailer", "-", "super-rounds", "sumV", "tokens", "p1 iters", "p2 iters",
-         "flush groups", "match steps", "fix-up rounds"]
-tot = s[:, :7].sum(axis=1).mean()
+         "flush groups", "match steps", "fix-up rounds", "fl:scan+lit", "fl:stepform", "fl:ownermap", "fl:memory", "fl:tail", "-", "-", "-"]
+tot = s[:, :7].sum(axis=1).mean() + s[:, 16:21].sum(axis=1).mean()
 print(f"kind={kind} units={n} kernel={a.elapsed_time(b):.3f} ms; mean cycles/unit {tot:.0f}")
 for i, nm in enumerate(names):
     if nm == "-":
         continue
     m = s[:, i].mean()
-    print(f"  {nm:14s} {m:12.1f}" + (f"  ({100 * m / tot:5.1f}%)" if i < 7 else ""))
+    print(f"  {nm:14s} {m:12.1f}" + (f"  ({100 * m / tot:5.1f}%)" if (i < 7 or i >= 16) else ""))
 print(f"  valid lanes per super-round: {s[:, 9].sum() / s[:, 8].sum():.2f}; tokens/unit {s[:, 10].mean():.0f}; "
       f"tokens per p2 iter {s[:, 10].sum() / s[:, 12].sum():.1f}; match steps per group {s[:, 14].sum() / s[:, 13].sum():.2f}")
