@@ -2,7 +2,6 @@
 #include "chip_internal.h"
 
 namespace chip {
-hipError_t launch_zstd_decode(const BatchArgs &, int, hipStream_t) { return hipErrorNotSupported; }
 hipError_t launch_deflate_l1(const BatchArgs &, hipStream_t) { return hipErrorNotSupported; }
 }  // namespace chip
 

@@ -1,0 +1,774 @@
+// Batched zstd frame decode for gfx950 (MI355X): one wavefront decodes one independent frame.
+//
+// Replaces, per frame, what compu reaches through ZSTD_decompressStream (src/decoder/zstd.rs:110) for
+// a decoder built by Interface::zstd(opts) (src/decoder/zstd.rs:81-94): frame header, block loop,
+// literals (raw / RLE / Huffman 1 or 4 streams / treeless), sequences (predefined / RLE / FSE /
+// repeat tables, three interleaved FSE states on a backward bitstream), sequence execution with the
+// repeat-offset history, and the XXH64 content checksum (RFC 8878).  No dictionaries (compu never
+// loads one).
+//
+// Layout: the Huffman and FSE decode tables live in LDS; regenerated Huffman literals are parked at
+// the END of the unit's output capacity (they are always consumed before the output cursor reaches
+// them, as in libzstd's in-destination literal buffer); raw literals are read in place from the
+// input; the match window is the output itself.
+#include "chip_internal.h"
+
+namespace chip {
+
+namespace {
+
+constexpr uint32_t BLOCK_MAX = 128u * 1024u;
+
+enum : int32_t { ZS_OK = 0 };
+
+// sequence code tables, RFC 8878 sec. 3.1.1.3.2.1.1
+__device__ const uint32_t LL_BASE[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+__device__ const uint8_t LL_BITS[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const uint32_t ML_BASE[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__device__ const uint8_t ML_BITS[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const int8_t LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ const int8_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+__device__ const int8_t ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+
+// FSE decode entry: [7:0] symbol, [15:8] number of bits to read, [31:16] baseline of the next state
+struct FseTab {
+    uint32_t e[512];
+    uint32_t al;
+    uint32_t valid;
+};
+
+struct alignas(16) ZLds {
+    uint16_t huf[2048];  // [7:0] symbol, [11:8] code length
+    FseTab ll, of, ml;
+    uint32_t huf_bits, huf_valid;
+    uint8_t weights[256];
+    int16_t norm[64];
+    uint16_t next[64];
+    FseTab wt;  // FSE table of the Huffman weights (accuracy <= 6; only e[0..63] used)
+};
+
+// the unit's input seen as dwords (aligned down), addressed by absolute bit index
+struct Bits {
+    const uint32_t *g32;
+    uint32_t total_dw;
+};
+
+__device__ __forceinline__ uint32_t rd32_at(const Bits &b, uint32_t bit)
+{
+    uint32_t i = bit >> 5;
+    uint32_t d0 = i < b.total_dw ? b.g32[i] : 0u;
+    uint32_t d1 = i + 1 < b.total_dw ? b.g32[i + 1] : 0u;
+    return __builtin_amdgcn_alignbit(d1, d0, bit & 31u);
+}
+
+// backward bitstream over absolute bit range [lo, pos): peek/read n <= 24 bits, MSB = the bit at pos-1;
+// bits below `lo` read as zero and `over` records that the stream was over-read
+struct BackBits {
+    uint32_t lo;
+    int32_t avail;  // unread bits (negative once over-read)
+};
+
+__device__ __forceinline__ uint32_t bb_peek(const Bits &b, const BackBits &s, uint32_t n)
+{
+    if (n == 0 || s.avail <= 0) return 0;
+    if ((uint32_t)s.avail >= n) return rd32_at(b, s.lo + (uint32_t)s.avail - n) & ((1u << n) - 1u);
+    return (rd32_at(b, s.lo) & ((1u << s.avail) - 1u)) << (n - (uint32_t)s.avail);
+}
+__device__ __forceinline__ uint32_t bb_read(const Bits &b, BackBits &s, uint32_t n)
+{
+    uint32_t v = bb_peek(b, s, n);
+    s.avail -= (int32_t)n;
+    return v;
+}
+
+// stream of `nbytes` bytes starting at absolute byte `byte0`; false if empty or its last byte is zero
+__device__ __forceinline__ bool bb_init(const Bits &b, BackBits &s, uint32_t byte0, uint32_t nbytes)
+{
+    if (nbytes == 0) return false;
+    uint32_t last = rd32_at(b, (byte0 + nbytes - 1) * 8u) & 0xffu;
+    if (last == 0) return false;
+    s.lo = byte0 * 8u;
+    s.avail = (int32_t)((nbytes - 1) * 8u + (31u - (uint32_t)__clz((int)last)));
+    return true;
+}
+
+__device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { return rd32_at(b, byte * 8u) & 0xffu; }
+
+// FSE table description (sec. 4.1.1) read forward from absolute byte `p0` (at most `n` bytes).
+// Fills L.norm; returns bytes consumed or -1.  Uniform.
+__device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, int max_al, int max_sym, int &al_out, int &nsym_out)
+{
+    if (n < 1) return -1;
+    uint32_t bit = p0 * 8u;
+    const uint32_t endbit = (p0 + n) * 8u;
+    int al = (int)(rd32_at(b, bit) & 15u) + 5;
+    bit += 4;
+    if (al > max_al) return -1;
+    int remaining = (1 << al) + 1, threshold = 1 << al, nbits = al + 1, sym = 0, prev0 = 0;
+    while (remaining > 1 && sym <= max_sym) {
+        if (prev0) {
+            int n0 = sym;
+            while ((rd32_at(b, bit) & 3u) == 3u) {
+                n0 += 3;
+                bit += 2;
+                if (bit > endbit + 7) return -1;
+            }
+            n0 += (int)(rd32_at(b, bit) & 3u);
+            bit += 2;
+            if (n0 > max_sym + 1) return -1;
+            while (sym < n0) {
+                if (lane_id() == 0) L.norm[sym] = 0;
+                sym++;
+            }
+            if (sym > max_sym) break;
+        }
+        int max = (2 * threshold - 1) - remaining, count;
+        uint32_t bits = rd32_at(b, bit);
+        if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
+            count = (int)(bits & (uint32_t)(threshold - 1));
+            bit += (uint32_t)(nbits - 1);
+        } else {
+            count = (int)(bits & (uint32_t)(2 * threshold - 1));
+            if (count >= threshold) count -= max;
+            bit += (uint32_t)nbits;
+        }
+        count--;
+        remaining -= count < 0 ? -count : count;
+        if (lane_id() == 0) L.norm[sym] = (int16_t)count;
+        sym++;
+        prev0 = !count;
+        while (remaining < threshold) {
+            nbits--;
+            threshold >>= 1;
+        }
+        if (bit > endbit + 7) return -1;
+    }
+    if (remaining != 1 || sym > max_sym + 1) return -1;
+    al_out = al;
+    nsym_out = sym;
+    uint32_t used = ((bit + 7u) >> 3) - p0;
+    if (used > n) return -1;
+    return (int)used;
+}
+
+// FSE decoding table from normalized counts in L.norm (sec. 4.1.1).  Uniform; lane 0 writes.
+__device__ int fse_build(ZLds &L, FseTab &t, int nsym, int al)
+{
+    WSYNC();
+    const bool w = lane_id() == 0;
+    int size = 1 << al, high = size - 1;
+    for (int s = 0; s < nsym; s++) {
+        int c = L.norm[s];
+        if (c == -1) {
+            if (w) t.e[high] = (uint32_t)s;
+            high--;
+            if (w) L.next[s] = 1;
+        } else if (w) L.next[s] = (uint16_t)c;
+    }
+    int step = (size >> 1) + (size >> 3) + 3, mask = size - 1, pos = 0;
+    for (int s = 0; s < nsym; s++) {
+        int c = L.norm[s];
+        for (int i = 0; i < c; i++) {
+            if (w) t.e[pos] = (uint32_t)s;
+            do {
+                pos = (pos + step) & mask;
+            } while (pos > high);
+        }
+    }
+    if (pos != 0) return -1;
+    WSYNC();
+    // each state's bit count and baseline depend on how many earlier states share its symbol
+    if (w) {
+        for (int u = 0; u < size; u++) {
+            uint32_t s = t.e[u] & 0xffu;
+            uint32_t ns = L.next[s];
+            L.next[s] = (uint16_t)(ns + 1);
+            uint32_t nb = (uint32_t)al - (31u - (uint32_t)__clz((int)ns));
+            t.e[u] = s | (nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xffffu) << 16);
+        }
+        t.al = (uint32_t)al;
+        t.valid = 1;
+    }
+    WSYNC();
+    return 0;
+}
+
+__device__ void fse_rle(FseTab &t, uint32_t sym)
+{
+    WSYNC();
+    if (lane_id() == 0) {
+        t.e[0] = sym;
+        t.al = 0;
+        t.valid = 1;
+    }
+    WSYNC();
+}
+
+template <int N>
+__device__ void load_default(ZLds &L, const int8_t (&def)[N])
+{
+    WSYNC();
+    if (lane_id() < (uint32_t)N) L.norm[lane_id()] = def[lane_id()];
+    WSYNC();
+}
+
+// Huffman decoding table from L.weights[0..n) (last weight implied), sec. 4.2.1.  Returns 0 / -1.
+__device__ int huf_build(ZLds &L, int n)
+{
+    WSYNC();
+    const uint32_t lane = lane_id();
+    uint32_t total = 0;
+    bool bad = false;
+    for (int i = 0; i < n; i++) {
+        uint32_t wv = L.weights[i];
+        if (wv > 11) bad = true;
+        if (wv) total += 1u << (wv - 1);
+    }
+    if (bad || total == 0) return -1;
+    int maxbits = 32 - __clz((int)total);
+    if (maxbits > 11) return -1;
+    uint32_t rest = (1u << maxbits) - total;
+    if (rest & (rest - 1)) return -1;
+    if (lane == 0) L.weights[n] = (uint8_t)(32 - __clz((int)rest));
+    n++;
+    WSYNC();
+    int cnt1 = 0;
+    for (int i = 0; i < n; i++) cnt1 += L.weights[i] == 1;
+    if (cnt1 < 2 || (cnt1 & 1)) return -1;
+    uint32_t pos = 0;
+    for (int wt = 1; wt <= maxbits; wt++) {
+        const uint32_t len = 1u << (wt - 1);
+        const uint16_t nbv = (uint16_t)((maxbits + 1 - wt) << 8);
+        for (int s = 0; s < n; s++) {
+            if (L.weights[s] != wt) continue;
+            for (uint32_t k = lane; k < len; k += 64) L.huf[pos + k] = (uint16_t)(s | nbv);
+            pos += len;
+        }
+    }
+    if (lane == 0) {
+        L.huf_bits = (uint32_t)maxbits;
+        L.huf_valid = 1;
+    }
+    WSYNC();
+    return 0;
+}
+
+// Huffman tree description at absolute byte p0 (<= n bytes): returns bytes consumed or -1.
+__device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
+{
+    if (n < 1) return -1;
+    const uint32_t hb = byte_at(b, p0);
+    int nw = 0;
+    uint32_t used;
+    WSYNC();
+    if (hb >= 128) {
+        nw = (int)hb - 127;
+        used = 1 + (uint32_t)(nw + 1) / 2;
+        if (used > n) return -1;
+        for (int i = lane_id(); i < nw; i += 64) {
+            uint32_t v = byte_at(b, p0 + 1 + (uint32_t)i / 2);
+            L.weights[i] = (uint8_t)((i & 1) ? (v & 15u) : (v >> 4));
+        }
+    } else {
+        used = 1 + hb;
+        if (hb == 0 || used > n) return -1;
+        int al, nsym;
+        int c = fse_read_ncount(L, b, p0 + 1, hb, 6, 12, al, nsym);
+        if (c < 0) return -1;
+        if (fse_build(L, L.wt, nsym, al)) return -1;
+        BackBits s;
+        if (!bb_init(b, s, p0 + 1 + (uint32_t)c, hb - (uint32_t)c)) return -1;
+        uint32_t s1 = bb_read(b, s, (uint32_t)al), s2 = bb_read(b, s, (uint32_t)al);
+        if (s.avail < 0) return -1;
+        const bool w = lane_id() == 0;
+        for (;;) {
+            if (nw > 253) return -1;
+            uint32_t e1 = L.wt.e[s1];
+            if (w) L.weights[nw] = (uint8_t)e1;
+            nw++;
+            s1 = (e1 >> 16) + bb_read(b, s, (e1 >> 8) & 0xffu);
+            if (s.avail < 0) {
+                if (w) L.weights[nw] = (uint8_t)L.wt.e[s2];
+                nw++;
+                break;
+            }
+            if (nw > 253) return -1;
+            uint32_t e2 = L.wt.e[s2];
+            if (w) L.weights[nw] = (uint8_t)e2;
+            nw++;
+            s2 = (e2 >> 16) + bb_read(b, s, (e2 >> 8) & 0xffu);
+            if (s.avail < 0) {
+                if (w) L.weights[nw] = (uint8_t)L.wt.e[s1];
+                nw++;
+                break;
+            }
+        }
+    }
+    if (nw > 255) return -1;
+    if (huf_build(L, nw)) return -1;
+    return (int)used;
+}
+
+// XXH64 (seed 0) of p[0..n): lanes 0..3 own the four accumulators.  Returns the low 32 bits.
+__device__ uint32_t wave_xxh64_low32(const uint8_t *p, uint32_t n)
+{
+    constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
+                       P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    auto rd64 = [&](uint32_t off) {
+        uint64_t v = 0;
+        for (int k = 7; k >= 0; k--) v = (v << 8) | p[off + (uint32_t)k];
+        return v;
+    };
+    auto round1 = [&](uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; };
+    const uint32_t lane = lane_id();
+    uint64_t h;
+    uint32_t off = 0;
+    if (n >= 32) {
+        uint64_t acc = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ULL : 0ULL - P1;
+        const uint32_t stripes = n >> 5;
+        if (lane < 4)
+            for (uint32_t i = 0; i < stripes; i++) acc = round1(acc, rd64(32u * i + 8u * lane));
+        off = stripes << 5;
+        uint64_t v[4];
+        for (int k = 0; k < 4; k++) {
+            uint32_t lo = rdlane((uint32_t)acc, (uint32_t)k), hi = rdlane((uint32_t)(acc >> 32), (uint32_t)k);
+            v[k] = ((uint64_t)hi << 32) | lo;
+        }
+        h = rotl(v[0], 1) + rotl(v[1], 7) + rotl(v[2], 12) + rotl(v[3], 18);
+        for (int k = 0; k < 4; k++) h = (h ^ round1(0, v[k])) * P1 + P4;
+    } else {
+        h = P5;
+    }
+    h += (uint64_t)n;
+    while (off + 8 <= n) {
+        h ^= round1(0, rd64(off));
+        h = rotl(h, 27) * P1 + P4;
+        off += 8;
+    }
+    if (off + 4 <= n) {
+        uint64_t v = 0;
+        for (int k = 3; k >= 0; k--) v = (v << 8) | p[off + (uint32_t)k];
+        h ^= v * P1;
+        h = rotl(h, 23) * P2 + P3;
+        off += 4;
+    }
+    while (off < n) {
+        h ^= (uint64_t)p[off] * P5;
+        h = rotl(h, 11) * P1;
+        off++;
+    }
+    h ^= h >> 33;
+    h *= P2;
+    h ^= h >> 29;
+    h *= P3;
+    h ^= h >> 32;
+    return (uint32_t)h;
+}
+
+// wave-cooperative forward copy of n bytes; dst and src may overlap with dst - src = period >= 1
+// (the LZ77 replicate case) or be disjoint
+__device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
+{
+    for (uint32_t j = lane_id(); j < n; j += 64) dst[j] = src[j];
+}
+
+__device__ void wave_match_copy(uint8_t *dst, uint32_t offset, uint32_t n)
+{
+    const uint32_t lane = lane_id();
+    const uint8_t *src = dst - offset;
+    if (offset >= n) {
+        for (uint32_t j = lane; j < n; j += 64) dst[j] = src[j];
+    } else if (offset >= 64) {
+        // chunks of 64 bytes never read what the same chunk writes
+        for (uint32_t base = 0; base < n; base += 64) {
+            uint32_t j = base + lane;
+            uint8_t v = j < n ? src[j] : (uint8_t)0;
+            if (j < n) dst[j] = v;
+        }
+    } else {
+        // short period: every byte is a copy of one of the `offset` bytes before dst
+        for (uint32_t j = lane; j < n; j += 64) dst[j] = src[j % offset];
+    }
+}
+
+__global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
+{
+    __shared__ ZLds L;
+    const uint32_t u = blockIdx.x;
+    if (u >= a.n) return;
+    const uint32_t lane = lane_id();
+    const uint8_t *gin = a.in_base + a.in_off[u];
+    const uint32_t in_len = a.in_len[u];
+    uint8_t *gout = a.out_base + a.out_off[u];
+    const uint32_t cap = a.out_cap[u];
+
+    Bits b;
+    const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);
+    b.g32 = (const uint32_t *)(gin - mis);
+    b.total_dw = (mis + in_len + 3u) >> 2;
+    const uint32_t B0 = mis;  // absolute byte index of the unit's first byte
+    const uint32_t END = mis + in_len;
+
+    int32_t status = ST_RUNNING;
+    uint32_t ip = B0;  // absolute byte cursor
+    uint32_t opos = 0;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    bool has_checksum = false, has_fcs = false;
+    uint64_t fcs = 0, window = 0, out_limit = ~0ULL;
+    if (lane == 0) {
+        L.huf_valid = 0;
+        L.ll.valid = L.of.valid = L.ml.valid = 0;
+    }
+    WSYNC();
+
+#define ZFAIL(code) do { status = -(code); goto done; } while (0)
+#define ZNEED_INPUT() do { status = CHIP_NEED_INPUT; goto done; } while (0)
+
+    // ---- frame header (sec. 3.1.1.1) ------------------------------------------------------------
+    {
+        if (END - ip < 4) ZNEED_INPUT();
+        uint32_t magic = rd32_at(b, ip * 8u);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame (sec. 3.1.2): a frame without content
+            if (END - ip < 8) ZNEED_INPUT();
+            uint32_t sz = rd32_at(b, (ip + 4) * 8u);
+            if ((uint64_t)(END - ip) < 8ull + sz) ZNEED_INPUT();
+            ip += 8 + sz;
+            status = CHIP_FINISHED;
+            goto done;
+        }
+        if (magic != 0xFD2FB528u) ZFAIL(ZSTD_E_PREFIX_UNKNOWN);
+        if (END - ip < 5) ZNEED_INPUT();
+        const uint32_t fhd = byte_at(b, ip + 4), fcs_flag = fhd >> 6, single = (fhd >> 5) & 1u, did_flag = fhd & 3u;
+        const uint32_t did_sz = did_flag == 3 ? 4u : did_flag, fsz = fcs_flag ? (1u << fcs_flag) : single;
+        const uint32_t hsz = 5 + (single ? 0u : 1u) + did_sz + fsz;
+        if (END - ip < hsz) ZNEED_INPUT();
+        if (fhd & 0x08u) ZFAIL(ZSTD_E_FRAMEPARAM_UNSUPPORTED);
+        uint32_t q = ip + 5;
+        if (!single) {
+            uint32_t wd = byte_at(b, q++);
+            uint32_t wlog = (wd >> 3) + 10;
+            if (wlog > 31) ZFAIL(ZSTD_E_WINDOW_TOO_LARGE);
+            window = 1ull << wlog;
+            window += (window >> 3) * (wd & 7u);
+        }
+        uint32_t did = 0;
+        for (uint32_t k = 0; k < did_sz; k++) did |= byte_at(b, q++) << (8 * k);
+        for (uint32_t k = 0; k < fsz; k++) fcs |= (uint64_t)byte_at(b, q++) << (8 * k);
+        if (fcs_flag == 1) fcs += 256;
+        has_fcs = fsz > 0;
+        if (single) window = fcs;
+        if (window > (1ull << wlog_max)) ZFAIL(ZSTD_E_WINDOW_TOO_LARGE);
+        if (did != 0) ZFAIL(ZSTD_E_DICT_WRONG);
+        has_checksum = (fhd >> 2) & 1u;
+        {
+            uint64_t bm = window < BLOCK_MAX ? window : BLOCK_MAX, ring = window + bm + 64;
+            if (has_fcs && fcs < ring) out_limit = fcs;  // libzstd's output buffer is no larger than the content size
+        }
+        ip += hsz;
+    }
+
+    // ---- blocks (sec. 3.1.1.2) --------------------------------------------------------------------
+    for (;;) {
+        if (END - ip < 3) ZNEED_INPUT();
+        const uint32_t bh = rd32_at(b, ip * 8u) & 0xffffffu;
+        const uint32_t last = bh & 1u, type = (bh >> 1) & 3u, bsz = bh >> 3;
+        const uint32_t bmax = window < BLOCK_MAX ? (uint32_t)window : BLOCK_MAX;
+        if (type == 3) ZFAIL(ZSTD_E_CORRUPTION);
+        if (bsz > bmax) ZFAIL(ZSTD_E_CORRUPTION);
+        if (type == 0) {  // raw block: streams through as far as the input goes
+            if ((uint64_t)opos + bsz > out_limit) ZFAIL(70);
+            ip += 3;
+            uint32_t avail = END - ip, k = bsz < avail ? bsz : avail;
+            if (k > cap - opos) {
+                status = CHIP_NEED_OUTPUT;
+                goto done;
+            }
+            wave_copy_bytes(gout + opos, (const uint8_t *)b.g32 + ip, k);
+            opos += k;
+            ip += k;
+            if (k < bsz) ZNEED_INPUT();
+        } else if (type == 1) {
+            if (END - ip < 4) ZNEED_INPUT();
+            if ((uint64_t)opos + bsz > out_limit) ZFAIL(70);
+            if (bsz > cap - opos) {
+                status = CHIP_NEED_OUTPUT;
+                goto done;
+            }
+            const uint8_t v = (uint8_t)byte_at(b, ip + 3);
+            for (uint32_t j = lane; j < bsz; j += 64) gout[opos + j] = v;
+            opos += bsz;
+            ip += 4;
+        } else {
+            if (END - ip < 3 + bsz) ZNEED_INPUT();
+            // ---- compressed block ----------------------------------------------------------------
+            const uint32_t bp = ip + 3, bend = bp + bsz;
+            if (bsz < 1) ZFAIL(ZSTD_E_CORRUPTION);
+            const uint32_t b0 = byte_at(b, bp), ltype = b0 & 3u, sf = (b0 >> 2) & 3u;
+            uint32_t hl, regen, comp = 0, streams = 1;
+            if (ltype < 2) {
+                if (sf == 0 || sf == 2) {
+                    hl = 1;
+                    regen = b0 >> 3;
+                } else if (sf == 1) {
+                    if (bsz < 2) ZFAIL(ZSTD_E_CORRUPTION);
+                    hl = 2;
+                    regen = (b0 >> 4) | (byte_at(b, bp + 1) << 4);
+                } else {
+                    if (bsz < 3) ZFAIL(ZSTD_E_CORRUPTION);
+                    hl = 3;
+                    regen = (b0 >> 4) | (byte_at(b, bp + 1) << 4) | (byte_at(b, bp + 2) << 12);
+                }
+            } else {
+                if (bsz < 5) ZFAIL(ZSTD_E_CORRUPTION);
+                const uint64_t v = (uint64_t)rd32_at(b, bp * 8u) | ((uint64_t)byte_at(b, bp + 4) << 32);
+                if (sf == 0 || sf == 1) {
+                    hl = 3;
+                    regen = (uint32_t)(v >> 4) & 0x3ffu;
+                    comp = (uint32_t)(v >> 14) & 0x3ffu;
+                    streams = sf ? 4 : 1;
+                } else if (sf == 2) {
+                    hl = 4;
+                    regen = (uint32_t)(v >> 4) & 0x3fffu;
+                    comp = (uint32_t)(v >> 18) & 0x3fffu;
+                    streams = 4;
+                } else {
+                    hl = 5;
+                    regen = (uint32_t)(v >> 4) & 0x3ffffu;
+                    comp = (uint32_t)(v >> 22) & 0x3ffffu;
+                    streams = 4;
+                }
+            }
+            if (regen > BLOCK_MAX) ZFAIL(ZSTD_E_CORRUPTION);
+            uint32_t p = bp + hl, left = bsz - hl;
+            // literal source: 0 = bytes in the input at lit_in, 1 = one repeated byte, 2 = parked at gout+lit_out
+            uint32_t lit_mode = 0, lit_in = 0, lit_out = 0, lit_rle = 0;
+            if (ltype == 0) {
+                if (regen > left) ZFAIL(ZSTD_E_CORRUPTION);
+                lit_in = p;
+                p += regen;
+                left -= regen;
+            } else if (ltype == 1) {
+                if (left < 1) ZFAIL(ZSTD_E_CORRUPTION);
+                lit_mode = 1;
+                lit_rle = byte_at(b, p);
+                p += 1;
+                left -= 1;
+            } else {
+                if (comp > left) ZFAIL(ZSTD_E_CORRUPTION);
+                uint32_t lp = p, lleft = comp;
+                if (ltype == 2) {
+                    int c = huf_read(L, b, lp, lleft);
+                    if (c < 0) ZFAIL(ZSTD_E_CORRUPTION);
+                    lp += (uint32_t)c;
+                    lleft -= (uint32_t)c;
+                } else if (!L.huf_valid) ZFAIL(30);  // treeless without a previous table: dictionary_corrupted
+                if (regen > cap - opos) {
+                    status = CHIP_NEED_OUTPUT;
+                    goto done;
+                }
+                lit_mode = 2;
+                lit_out = cap - regen;
+                uint32_t sz[4] = {lleft, 0, 0, 0}, cnt[4] = {regen, 0, 0, 0};
+                uint32_t st0 = lp;
+                if (streams == 4) {
+                    if (lleft < 10) ZFAIL(ZSTD_E_CORRUPTION);
+                    uint32_t j0 = rd32_at(b, lp * 8u), j1 = rd32_at(b, (lp + 4) * 8u);
+                    sz[0] = j0 & 0xffffu;
+                    sz[1] = j0 >> 16;
+                    sz[2] = j1 & 0xffffu;
+                    if (6 + sz[0] + sz[1] + sz[2] > lleft) ZFAIL(ZSTD_E_CORRUPTION);
+                    sz[3] = lleft - 6 - sz[0] - sz[1] - sz[2];
+                    const uint32_t seg = (regen + 3) / 4;
+                    if (seg * 3 > regen) ZFAIL(ZSTD_E_CORRUPTION);
+                    cnt[0] = cnt[1] = cnt[2] = seg;
+                    cnt[3] = regen - 3 * seg;
+                    st0 = lp + 6;
+                }
+                // lanes 0..3 each decode one stream, symbol by symbol
+                bool sbad = false;
+                if (lane < streams) {
+                    uint32_t myoff = st0, myout = lit_out;
+                    for (uint32_t k = 0; k < lane; k++) {
+                        myoff += sz[k];
+                        myout += cnt[k];
+                    }
+                    BackBits s;
+                    if (!bb_init(b, s, myoff, sz[lane])) sbad = true;
+                    else {
+                        const uint32_t hbits = L.huf_bits;
+                        const uint32_t ncnt = cnt[lane];
+                        for (uint32_t i = 0; i < ncnt; i++) {
+                            uint32_t e = L.huf[bb_peek(b, s, hbits)];
+                            gout[myout + i] = (uint8_t)e;
+                            s.avail -= (int32_t)(e >> 8);
+                            if (s.avail < 0) {
+                                sbad = true;
+                                break;
+                            }
+                        }
+                        if (s.avail != 0) sbad = true;  // the stream must be consumed exactly
+                    }
+                }
+                if (__any(sbad)) ZFAIL(ZSTD_E_CORRUPTION);
+                p += comp;
+                left -= comp;
+            }
+            // ---- sequences section (sec. 3.1.1.3.2) ---------------------------------------------
+            if (left < 1) ZFAIL(ZSTD_E_CORRUPTION);
+            uint32_t nseq = byte_at(b, p);
+            if (nseq < 128) {
+                p += 1;
+                left -= 1;
+            } else if (nseq < 255) {
+                if (left < 2) ZFAIL(ZSTD_E_CORRUPTION);
+                nseq = ((nseq - 128) << 8) + byte_at(b, p + 1);
+                p += 2;
+                left -= 2;
+            } else {
+                if (left < 3) ZFAIL(ZSTD_E_CORRUPTION);
+                nseq = byte_at(b, p + 1) + (byte_at(b, p + 2) << 8) + 0x7F00u;
+                p += 3;
+                left -= 3;
+            }
+            const uint32_t block_out0 = opos;
+            uint32_t lpos = 0;
+            auto copy_literals = [&](uint32_t n) {
+                if (lit_mode == 0) wave_copy_bytes(gout + opos, (const uint8_t *)b.g32 + lit_in + lpos, n);
+                else if (lit_mode == 1)
+                    for (uint32_t j = lane; j < n; j += 64) gout[opos + j] = (uint8_t)lit_rle;
+                else wave_copy_bytes(gout + opos, gout + lit_out + lpos, n);
+            };
+            if (nseq == 0) {
+                if (left != 0) ZFAIL(ZSTD_E_CORRUPTION);
+            } else {
+                if (left < 1) ZFAIL(ZSTD_E_CORRUPTION);
+                const uint32_t modes = byte_at(b, p);
+                p += 1;
+                left -= 1;
+                if (modes & 3u) ZFAIL(ZSTD_E_CORRUPTION);
+                for (int k = 0; k < 3; k++) {
+                    FseTab &t = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+                    const int maxal = k == 1 ? 8 : 9, maxsym = k == 0 ? 35 : k == 1 ? 31 : 52;
+                    const uint32_t mode = (modes >> (6 - 2 * k)) & 3u;
+                    if (mode == 0) {
+                        if (k == 0) load_default(L, LL_DEF);
+                        else if (k == 1) load_default(L, OF_DEF);
+                        else load_default(L, ML_DEF);
+                        if (fse_build(L, t, k == 0 ? 36 : k == 1 ? 29 : 53, k == 1 ? 5 : 6)) ZFAIL(ZSTD_E_CORRUPTION);
+                    } else if (mode == 1) {
+                        if (left < 1) ZFAIL(ZSTD_E_CORRUPTION);
+                        uint32_t sym = byte_at(b, p);
+                        if (sym > (uint32_t)maxsym) ZFAIL(ZSTD_E_CORRUPTION);
+                        fse_rle(t, sym);
+                        p += 1;
+                        left -= 1;
+                    } else if (mode == 2) {
+                        int al, nsym;
+                        int c = fse_read_ncount(L, b, p, left, maxal, maxsym, al, nsym);
+                        if (c < 0) ZFAIL(ZSTD_E_CORRUPTION);
+                        if (fse_build(L, t, nsym, al)) ZFAIL(ZSTD_E_CORRUPTION);
+                        p += (uint32_t)c;
+                        left -= (uint32_t)c;
+                    } else if (!t.valid) ZFAIL(ZSTD_E_CORRUPTION);
+                }
+                WSYNC();
+                BackBits s;
+                if (!bb_init(b, s, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
+                uint32_t sl = bb_read(b, s, L.ll.al), so = bb_read(b, s, L.of.al), sm = bb_read(b, s, L.ml.al);
+                if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
+                for (uint32_t i = 0; i < nseq; i++) {
+                    const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
+                    const uint32_t oc = eo & 0xffu, mc = em & 0xffu, lc = el & 0xffu;
+                    if (oc > 31) ZFAIL(ZSTD_E_CORRUPTION);
+                    // offset bits can exceed 24: read in two parts
+                    uint32_t obits = oc > 16 ? (bb_read(b, s, oc - 16) << 16) | bb_read(b, s, 16) : bb_read(b, s, oc);
+                    const uint64_t ov = (1ull << oc) + obits;
+                    const uint32_t mlen = ML_BASE[mc] + bb_read(b, s, ML_BITS[mc]);
+                    const uint32_t llen = LL_BASE[lc] + bb_read(b, s, LL_BITS[lc]);
+                    uint64_t offset;
+                    if (ov > 3) {
+                        offset = ov - 3;
+                        rep2 = rep1;
+                        rep1 = rep0;
+                        rep0 = (uint32_t)offset;
+                    } else {
+                        const uint32_t idx = (uint32_t)ov - (llen != 0 ? 1u : 0u);  // 3 means rep0 - 1
+                        if (idx == 0) offset = rep0;
+                        else {
+                            uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                            t += !t;
+                            if (idx != 1) rep2 = rep1;
+                            rep1 = rep0;
+                            rep0 = t;
+                            offset = t;
+                        }
+                    }
+                    if (i + 1 < nseq) {
+                        sl = (el >> 16) + bb_read(b, s, (el >> 8) & 0xffu);
+                        sm = (em >> 16) + bb_read(b, s, (em >> 8) & 0xffu);
+                        so = (eo >> 16) + bb_read(b, s, (eo >> 8) & 0xffu);
+                    }
+                    if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
+                    // execute: destination room, literal supply, offset (libzstd's order of verdicts)
+                    if ((uint64_t)opos + llen + mlen > out_limit) ZFAIL(70);
+                    if ((uint64_t)(opos - block_out0) + llen + mlen > BLOCK_MAX) ZFAIL(70);
+                    if (llen > regen - lpos) ZFAIL(ZSTD_E_CORRUPTION);
+                    if ((uint64_t)opos + llen + mlen > cap) {
+                        opos = block_out0;  // whole blocks only: see include/compu_hip.h
+                        status = CHIP_NEED_OUTPUT;
+                        goto done;
+                    }
+                    copy_literals(llen);
+                    opos += llen;
+                    lpos += llen;
+                    if (offset > opos) ZFAIL(ZSTD_E_CORRUPTION);
+                    wave_match_copy(gout + opos, (uint32_t)offset, mlen);
+                    opos += mlen;
+                }
+                if (s.avail != 0) ZFAIL(ZSTD_E_CORRUPTION);  // the bitstream must be consumed exactly
+            }
+            const uint32_t restl = regen - lpos;
+            if ((uint64_t)opos + restl > out_limit) ZFAIL(70);
+            if ((uint64_t)(opos - block_out0) + restl > BLOCK_MAX) ZFAIL(70);
+            if ((uint64_t)opos + restl > cap) {
+                opos = block_out0;
+                status = CHIP_NEED_OUTPUT;
+                goto done;
+            }
+            copy_literals(restl);
+            opos += restl;
+            ip = bend;
+        }
+        if (last) {
+            if (has_fcs && (uint64_t)opos != fcs) ZFAIL(ZSTD_E_CORRUPTION);
+            break;
+        }
+    }
+    if (has_checksum) {
+        if (END - ip < 4) ZNEED_INPUT();
+        uint32_t want = rd32_at(b, ip * 8u);
+        if (wave_xxh64_low32(gout, opos) != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);
+        ip += 4;
+    }
+    status = CHIP_FINISHED;
+done:
+    if (lane == 0) {
+        a.out_len[u] = opos;
+        a.in_used[u] = status == CHIP_NEED_INPUT ? in_len : ip - B0;
+        a.status[u] = status;
+    }
+#undef ZFAIL
+#undef ZNEED_INPUT
+}
+
+}  // namespace
+
+hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    hipLaunchKernelGGL(zstd_kernel, dim3(a.n), dim3(64), 0, stream, a, window_log_max ? window_log_max : 27);
+    return hipGetLastError();
+}
+
+}  // namespace chip

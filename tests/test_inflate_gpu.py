@@ -22,7 +22,7 @@ def _pack(parts):
     return buf, offs, lens
 
 
-def run_batch(torch, fmt, parts, caps):
+def run_batch(torch, fmt, parts, caps, check_tail=True):
     """Decode `parts` in one launch; returns (list of outputs, out_len, in_used, status) on the host."""
     import compu_amd
 
@@ -44,8 +44,10 @@ def run_batch(torch, fmt, parts, caps):
     outs = [bytes(h_out[ooff[i] : ooff[i] + ol[i]]) for i in range(len(parts))]
     # bytes behind each unit's produced range must be untouched (poison intact)
     for i in range(len(parts)):
-        tail = h_out[ooff[i] + ol[i] : ooff[i] + ((caps[i] + 15) & ~15)]
-        assert (tail == 0xA5).all(), f"unit {i}: wrote past out_len"
+        # zstd parks regenerated literals at the end of the unit's capacity (documented scratch use)
+        lo = ooff[i] + (ol[i] if check_tail else caps[i])
+        tail = h_out[lo : ooff[i] + ((caps[i] + 15) & ~15)]
+        assert (tail == 0xA5).all(), f"unit {i}: wrote past its output range"
     return outs, ol, iu, st
 
 

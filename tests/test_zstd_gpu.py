@@ -1,0 +1,118 @@
+"""zstd frame decode on the GPU: the reference's decoder test (tests/decoder.rs:119-128,
+should_decode_zstd) against the hip variant, and batch parity with the oracle."""
+import random
+
+import numpy as np
+import pytest
+
+import zstd_ref
+from conftest import golden
+from test_decoder_gpu import DATA, _test_case
+from test_inflate_gpu import _mk, run_batch
+
+pytestmark = pytest.mark.gpu
+FMT_ZSTD = 100
+
+
+def oracle_zstd_batch(parts, caps):
+    from oracle import oracle as O
+
+    res = []
+    for p, c in zip(parts, caps):
+        got, ir, orr, st, err = O.ZstdDecoder().decode(p, int(c))
+        res.append((got, len(p) - ir, err if err else st))
+    return res
+
+
+def test_should_decode_zstd_hip(gpu):
+    """tests/decoder.rs:119-128 with Interface::zstd replaced by the hip variant"""
+    import compu_amd
+
+    decoder = compu_amd.decoder_interface.zstd_hip(compu_amd.ZstdOptions())
+    assert decoder is not None, "create zstd-hip decoder"
+    for name in DATA:
+        _test_case(compu_amd, decoder, golden(name), golden(name + ".compressed.zstd"))
+    assert decoder.describe_error(compu_amd.DecodeError.no_error()) == "No error detected"
+
+
+def test_zstd_fixture_error_classes(gpu, alice):
+    import compu_amd
+
+    comp = golden("alice29.txt.compressed.zstd")
+    dec = compu_amd.decoder_interface.zstd_hip()
+    out = bytearray(len(alice) + 16)
+    bad = bytearray(comp)
+    bad[-1] ^= 1  # checksum mismatch -> Err(-22)
+    r = dec.decode(bytes(bad), out)
+    assert not r.is_ok() and r.status.as_raw() == -22
+    assert dec.describe_error(r.status) == "Restored data doesn't match checksum"
+    dec.reset()
+    r = dec.decode(b"\x00\x01\x02\x03\x04\x05", out)  # not a zstd frame -> Err(-10)
+    assert not r.is_ok() and r.status.as_raw() == -10
+    dec.reset()
+    r = dec.decode(comp[: len(comp) // 2], out)  # first half: the complete blocks come out, then NeedInput
+    assert r.status == compu_amd.DecodeStatus.NeedInput and r.input_remain == 0
+    n1 = len(out) - r.output_remain
+    assert bytes(out[:n1]) == alice[:n1] and n1 > 0
+    r = dec.decode(comp[len(comp) // 2 :] + b"xy", out, n1, len(out) - n1)
+    assert r.status == compu_amd.DecodeStatus.Finished and r.input_remain == 2
+    assert bytes(out[: len(alice)]) == alice
+    # window_log cap (ZstdOptions::window_log, src/decoder/zstd.rs:36-47): the fixture needs 152089 > 2^17
+    small = compu_amd.decoder_interface.zstd_hip(compu_amd.ZstdOptions().window_log(17))
+    r = small.decode(comp, out)
+    assert not r.is_ok() and r.status.as_raw() == -16
+
+
+def test_generated_frames_batch_match_oracle(gpu, alice):
+    z = zstd_ref.load()
+    assert z is not None
+    rnd = random.Random(8)
+    datas, parts = [], []
+    for it in range(250):
+        n = rnd.choice([0, 1, 2, 10, 100, 1000, 5000, 65536, 70000, 140000])
+        data = _mk(rnd.randrange(5), n, rnd, alice)
+        comp = zstd_ref.compress(z, data, rnd.choice([1, 3, 5, 9, 15, 19, -1]), rnd.random() < 0.7, rnd.random() < 0.8)
+        if it % 10 == 0:
+            comp = b"\x50\x2a\x4d\x18\x03\x00\x00\x00abc"  # a skippable frame: finished with no output
+            data = b""
+        datas.append(data)
+        parts.append(comp + (b"tail" if it % 3 == 0 else b""))
+    caps = [len(d) + rnd.choice([0, 0, 9, 200]) for d in datas]
+    outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, parts, [max(c, 1) for c in caps], check_tail=False)
+    ref = oracle_zstd_batch(parts, [max(c, 1) for c in caps])
+    for i in range(len(parts)):
+        assert st[i] == 2 == ref[i][2], (i, st[i], ref[i][2])
+        assert outs[i] == datas[i] == ref[i][0], i
+        assert iu[i] == ref[i][1], (i, iu[i], ref[i][1])
+
+
+def test_truncated_and_corrupt_frames_match_oracle(gpu, alice):
+    z = zstd_ref.load()
+    rnd = random.Random(12)
+    parts, caps = [], []
+    for it in range(600):
+        n = rnd.choice([50, 500, 5000, 70000])
+        data = _mk(rnd.choice([1, 2, 4, 0]), n, rnd, alice)
+        comp = bytearray(zstd_ref.compress(z, data, rnd.choice([1, 3, 9]), rnd.random() < 0.7, rnd.random() < 0.8))
+        mode = rnd.randrange(3)
+        if mode == 0:
+            comp[rnd.randrange(len(comp))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            comp = comp[: rnd.randrange(len(comp))]
+        parts.append(bytes(comp))
+        caps.append(n + 300)
+    outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, parts, caps, check_tail=False)
+    ref = oracle_zstd_batch(parts, caps)
+    for i in range(len(parts)):
+        r_out, r_used, r_st = ref[i]
+        if r_st == 1:
+            # the corrupted frame regenerates more than the capacity: the oracle hands out bytes up to
+            # the capacity, the batch kernel counts whole blocks only (include/compu_hip.h)
+            assert st[i] in (1, -70, -20), (i, st[i])
+            assert outs[i] == r_out[: len(outs[i])]
+            continue
+        assert st[i] == r_st, (i, st[i], r_st)
+        if r_st in (0, 2):
+            assert outs[i] == r_out, (i, len(outs[i]), len(r_out))
+        if r_st == 2:
+            assert iu[i] == r_used
