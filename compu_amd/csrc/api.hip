@@ -430,3 +430,228 @@ void chip_decoder_free(chip_decoder *d)
 }
 
 }  // extern "C"
+
+// ---- batched encode --------------------------------------------------------------------------------
+
+extern "C" {
+
+size_t chip_encode_bound(int format, size_t in_len)
+{
+    size_t blocks = in_len ? (in_len + 65534) / 65535 : 1;
+    size_t wrap = format == CHIP_FMT_GZIP ? 18 : format == CHIP_FMT_ZLIB ? 6 : 0;
+    return in_len + 5 * blocks + 5 + wrap;
+}
+
+int chip_encode_batch(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                      void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
+                      void *stream)
+{
+    if (n == 0) return CHIP_OK;
+    if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !status ||
+        level < 0 || level > 9 || (format != CHIP_FMT_DEFLATE && format != CHIP_FMT_ZLIB && format != CHIP_FMT_GZIP))
+        return CHIP_E_INVALID;
+    if (!device_ok()) return CHIP_E_NO_DEVICE;
+    BatchArgs a;
+    a.in_base = (const uint8_t *)in_base;
+    a.in_off = in_off;
+    a.in_len = in_len;
+    a.out_base = (uint8_t *)out_base;
+    a.out_off = out_off;
+    a.out_cap = out_cap;
+    a.out_len = out_len;
+    a.in_used = nullptr;
+    a.status = status;
+    a.n = (uint32_t)n;
+    a.format = format;
+    a.stats = nullptr;
+    hipError_t e = launch_deflate_l1(a, level, 7u, format == CHIP_FMT_ZLIB ? 1u : 0u, 0, nullptr, (hipStream_t)stream);
+    return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
+}
+
+}  // extern "C"
+
+// ---- streaming encoder -----------------------------------------------------------------------------
+// Same contract as internal_zlib_impl_encode! (src/encoder/mod.rs:334-370): Process buffers input,
+// Flush / Finish compress what is buffered as one byte-aligned deflate segment on the GPU (a sync
+// marker or the final-block flag closes it), and compressed bytes are handed out as the caller
+// provides room.
+
+struct chip_encoder {
+    int mode, level, device;
+    hipStream_t stream;
+    uint8_t *h_in;  // pinned: input not yet compressed
+    size_t h_in_cap, h_in_len;
+    uint8_t *d_in, *d_out;
+    size_t d_in_cap, d_out_cap;
+    uint8_t *h_out;  // pinned: compressed bytes not yet delivered
+    size_t h_out_cap, h_out_len, delivered;
+    struct EMeta {
+        uint64_t in_off, out_off;
+        uint32_t in_len, out_cap, out_len;
+        int32_t status;
+        uint32_t check, pad;
+    } *d_meta, *h_meta;
+    bool started, finished;
+    uint32_t check;
+    uint64_t total_in;
+};
+
+namespace {
+
+bool enc_reserve(uint8_t **buf, size_t *cap, size_t len, size_t need)
+{
+    if (need <= *cap) return true;
+    size_t c = *cap ? *cap : 65536;
+    while (c < need) c *= 2;
+    uint8_t *p = (uint8_t *)chip_pinned_alloc(c);
+    if (!p) return false;
+    if (len) memcpy(p, *buf, len);
+    chip_pinned_free(*buf);
+    *buf = p;
+    *cap = c;
+    return true;
+}
+
+void enc_clear(chip_encoder *e)
+{
+    e->h_in_len = 0;
+    e->h_out_len = e->delivered = 0;
+    e->started = e->finished = false;
+    e->check = e->mode == CHIP_FMT_ZLIB ? 1u : 0u;
+    e->total_in = 0;
+}
+
+// compress the buffered input as one segment and append it to h_out
+bool enc_segment(chip_encoder *e, bool final)
+{
+    if (hipSetDevice(e->device) != hipSuccess) return false;
+    const size_t n = e->h_in_len;
+    const size_t bound = chip_encode_bound(e->mode, n) + 16;
+    if (n + 16 > e->d_in_cap) {
+        chip_device_free(e->d_in);
+        e->d_in_cap = (n + 16) * 2;
+        e->d_in = (uint8_t *)chip_device_alloc(e->d_in_cap);
+        if (!e->d_in) return false;
+    }
+    if (bound > e->d_out_cap) {
+        chip_device_free(e->d_out);
+        e->d_out_cap = bound * 2;
+        e->d_out = (uint8_t *)chip_device_alloc(e->d_out_cap);
+        if (!e->d_out) return false;
+    }
+    if (n && hipMemcpyAsync(e->d_in, e->h_in, n, hipMemcpyHostToDevice, e->stream) != hipSuccess) return false;
+    chip_encoder::EMeta m = {0, 0, (uint32_t)n, (uint32_t)bound, 0, 0, 0, 0};
+    *e->h_meta = m;
+    if (hipMemcpyAsync(e->d_meta, e->h_meta, sizeof m, hipMemcpyHostToDevice, e->stream) != hipSuccess) return false;
+    BatchArgs a;
+    a.in_base = e->d_in;
+    a.in_off = &e->d_meta->in_off;
+    a.in_len = &e->d_meta->in_len;
+    a.out_base = e->d_out;
+    a.out_off = &e->d_meta->out_off;
+    a.out_cap = &e->d_meta->out_cap;
+    a.out_len = &e->d_meta->out_len;
+    a.in_used = nullptr;
+    a.status = &e->d_meta->status;
+    a.n = 1;
+    a.format = e->mode;
+    a.stats = nullptr;
+    const uint32_t flags = (e->started ? 0u : 1u) | (final ? 2u | 4u : 0u);
+    if (launch_deflate_l1(a, e->level, flags, e->check, e->total_in, &e->d_meta->check, e->stream) != hipSuccess) return false;
+    if (hipMemcpyAsync(e->h_meta, e->d_meta, sizeof m, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return false;
+    if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
+    if (e->h_meta->status != CHIP_ENC_FINISHED) return false;
+    const size_t got = e->h_meta->out_len;
+    if (!enc_reserve(&e->h_out, &e->h_out_cap, e->h_out_len, e->h_out_len + got)) return false;
+    if (got && (hipMemcpyAsync(e->h_out + e->h_out_len, e->d_out, got, hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+                hipStreamSynchronize(e->stream) != hipSuccess))
+        return false;
+    e->h_out_len += got;
+    e->check = e->h_meta->check;
+    e->total_in += n;
+    e->h_in_len = 0;
+    e->started = true;
+    if (final) e->finished = true;
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+chip_encoder *chip_encoder_new(const chip_encoder_opts *opts)
+{
+    int mode = opts ? opts->mode : CHIP_FMT_GZIP, level = opts ? opts->compression : 9;
+    if ((mode != CHIP_FMT_DEFLATE && mode != CHIP_FMT_ZLIB && mode != CHIP_FMT_GZIP) || level < 0 || level > 9) return nullptr;
+    if (!device_ok()) return nullptr;  // no CPU codec behind this backend
+    int device = opts ? opts->device : -1;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    chip_encoder *e = (chip_encoder *)host_alloc(sizeof(chip_encoder));
+    if (!e) return nullptr;
+    memset(e, 0, sizeof *e);
+    e->mode = mode;
+    e->level = level;
+    e->device = device;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
+        host_free(e);
+        return nullptr;
+    }
+    e->d_meta = (chip_encoder::EMeta *)chip_device_alloc(sizeof(chip_encoder::EMeta));
+    e->h_meta = (chip_encoder::EMeta *)chip_pinned_alloc(sizeof(chip_encoder::EMeta));
+    if (!e->d_meta || !e->h_meta || !enc_reserve(&e->h_in, &e->h_in_cap, 0, 65536) || !enc_reserve(&e->h_out, &e->h_out_cap, 0, 65536)) {
+        chip_encoder_free(e);
+        return nullptr;
+    }
+    enc_clear(e);
+    return e;
+}
+
+chip_encode_result chip_encode(chip_encoder *e, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int op)
+{
+    chip_encode_result r = {in_len, out_len, CHIP_ENC_ERROR};
+    if (!e || op < CHIP_OP_PROCESS || op > CHIP_OP_FINISH) return r;
+    size_t taken = 0;
+    if (!e->finished && in_len) {
+        if (!enc_reserve(&e->h_in, &e->h_in_cap, e->h_in_len, e->h_in_len + in_len)) return r;
+        memcpy(e->h_in + e->h_in_len, in, in_len);
+        e->h_in_len += in_len;
+        taken = in_len;
+    }
+    if (!e->finished && (op == CHIP_OP_FLUSH || op == CHIP_OP_FINISH) && (e->h_in_len || op == CHIP_OP_FINISH || !e->started)) {
+        if (!enc_segment(e, op == CHIP_OP_FINISH)) return r;
+    }
+    size_t avail = e->h_out_len - e->delivered, k = avail < out_len ? avail : out_len;
+    if (k) memcpy(out, e->h_out + e->delivered, k);
+    e->delivered += k;
+    if (e->delivered == e->h_out_len) e->h_out_len = e->delivered = 0;
+    r.input_remain = in_len - taken;
+    r.output_remain = out_len - k;
+    // deflate() return code -> EncodeStatus, src/encoder/mod.rs:357-367: with Finish, anything short of
+    // Z_STREAM_END is NeedOutput; otherwise Z_OK is Continue and a call without progress (Z_BUF_ERROR) NeedOutput
+    if (op == CHIP_OP_FINISH) r.status = (e->finished && e->h_out_len == 0) ? CHIP_ENC_FINISHED : CHIP_ENC_NEED_OUTPUT;
+    else r.status = (taken || k) ? CHIP_ENC_CONTINUE : CHIP_ENC_NEED_OUTPUT;
+    return r;
+}
+
+chip_encoder *chip_encoder_reset(chip_encoder *e)
+{
+    if (e) enc_clear(e);
+    return e;
+}
+
+void chip_encoder_free(chip_encoder *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    chip_pinned_free(e->h_in);
+    chip_pinned_free(e->h_out);
+    chip_pinned_free(e->h_meta);
+    chip_device_free(e->d_in);
+    chip_device_free(e->d_out);
+    chip_device_free(e->d_meta);
+    host_free(e);
+}
+
+}  // extern "C"

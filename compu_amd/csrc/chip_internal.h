@@ -44,7 +44,8 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);
 hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_t stream);
 hipError_t launch_detect(size_t n, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
                          hipStream_t stream);
-hipError_t launch_deflate_l1(const BatchArgs &a, hipStream_t stream);
+hipError_t launch_deflate_l1(const BatchArgs &a, int level, uint32_t flags, uint32_t check_seed, uint64_t total_before,
+                             uint32_t *check_out, hipStream_t stream);
 
 // ---- wavefront helpers (wave = 64 lanes, one wave per workgroup in the codec kernels) ----------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }

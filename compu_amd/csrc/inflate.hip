@@ -11,6 +11,7 @@
 //   LZ77 copies straight into the unit's output range in HBM (the window is the output itself,
 //   L2-resident for a 64 KiB unit).
 #include "chip_internal.h"
+#include "wave_checksums.h"
 
 namespace chip {
 
@@ -261,92 +262,6 @@ __device__ __forceinline__ void win_bits(const WaveLds &L, const InWin &w, uint3
 
 __device__ __forceinline__ uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 
-
-// ---- checksums over bytes in HBM, wave-parallel ------------------------------------------------
-// x^(2^k) mod P for the reflected CRC-32 polynomial 0xEDB88320 (bit 31 = x^0)
-__device__ const uint32_t X2N[32] = {
-    0x40000000u, 0x20000000u, 0x08000000u, 0x00800000u, 0x00008000u, 0xedb88320u, 0xb1e6b092u, 0xa06a2517u,
-    0xed627daeu, 0x88d14467u, 0xd7bbfe6au, 0xec447f11u, 0x8e7ea170u, 0x6427800eu, 0x4d47bae0u, 0x09fe548fu,
-    0x83852d0fu, 0x30362f1au, 0x7b5a9cc3u, 0x31fec169u, 0x9fec022au, 0x6c8dedc4u, 0x15d6874du, 0x5fde7a4eu,
-    0xbad90e37u, 0x2e4e5eefu, 0x4eaba214u, 0xa8a472c0u, 0x429a969eu, 0x148d302au, 0xc40ba6d0u, 0xc4e22c3cu};
-
-// a(x) * b(x) mod P, reflected representation
-__device__ __forceinline__ uint32_t multmodp(uint32_t a, uint32_t b)
-{
-    uint32_t p = 0;
-#pragma unroll 8
-    for (int i = 0; i < 32; i++) {
-        p ^= (a & (0x80000000u >> i)) ? b : 0u;
-        b = (b >> 1) ^ ((b & 1u) ? 0xEDB88320u : 0u);
-    }
-    return p;
-}
-
-// Split [0,n) into 64 right-aligned chunks of `chunk` bytes (chunk = power of two >= n/64): lane i
-// gets [beg,end); leading lanes may be empty and the first non-empty one may be short.
-__device__ __forceinline__ void lane_chunk(uint32_t n, uint32_t &chunk_log2, uint32_t &beg, uint32_t &end)
-{
-    uint32_t per = (n + 63u) >> 6;
-    chunk_log2 = per <= 1 ? 0u : 32u - (uint32_t)__clz((int)(per - 1));
-    uint64_t chunk = 1ull << chunk_log2;
-    int64_t e = (int64_t)n - (int64_t)(63 - (int64_t)lane_id()) * (int64_t)chunk;
-    int64_t b = e - (int64_t)chunk;
-    end = e > 0 ? (uint32_t)e : 0u;
-    beg = b > 0 ? (uint32_t)b : 0u;
-}
-
-// CRC-32 (RFC 1952 sec. 8) of p[0..n).  `tab` is 256 words of LDS scratch.
-__device__ uint32_t wave_crc32(uint32_t *tab, const uint8_t *p, uint32_t n)
-{
-    const uint32_t lane = lane_id();
-    WSYNC();
-    for (uint32_t i = lane; i < 256; i += 64) {
-        uint32_t c = i;
-#pragma unroll
-        for (int k = 0; k < 8; k++) c = (c >> 1) ^ ((c & 1u) ? 0xEDB88320u : 0u);
-        tab[i] = c;
-    }
-    WSYNC();
-    uint32_t lg, beg, end;
-    lane_chunk(n, lg, beg, end);
-    uint32_t c = (beg == 0 && end > 0) ? 0xffffffffu : 0u;  // the lane that owns byte 0 carries the preset
-    if (n == 0 && lane == 63) c = 0xffffffffu;
-    for (uint32_t k = beg; k < end; k++) c = tab[(c ^ p[k]) & 0xffu] ^ (c >> 8);
-    // tree combine: state(A||B) = state(A) * x^(8|B|) + raw(B); right blocks have 2^k * chunk bytes
-#pragma unroll
-    for (int k = 0; k < 6; k++) {
-        uint32_t left = (uint32_t)__shfl_up((int)c, 1 << k, 64);
-        uint32_t f = X2N[(3 + lg + k) & 31];
-        uint32_t comb = multmodp(f, left) ^ c;
-        if ((lane & ((2u << k) - 1)) == ((2u << k) - 1)) c = comb;
-    }
-    WSYNC();
-    return ~rdlane(c, 63);
-}
-
-// Adler-32 (RFC 1950 sec. 9) of p[0..n)
-__device__ uint32_t wave_adler32(const uint8_t *p, uint32_t n)
-{
-    uint32_t lg, beg, end;
-    lane_chunk(n, lg, beg, end);
-    uint32_t a = 0, b = 0, k = beg;
-    while (k < end) {
-        uint32_t stop = end - k > 2048 ? k + 2048 : end;
-        for (; k < stop; k++) {
-            a += p[k];
-            b += a;
-        }
-        a %= 65521u;
-        b %= 65521u;
-    }
-    // B_total = sum_i (b_i + a_i * bytes_after_i) + n ; A_total = 1 + sum a_i
-    uint64_t after = (uint64_t)(n - end);
-    uint32_t term = (uint32_t)(((uint64_t)b + (uint64_t)a * (after % 65521u)) % 65521u);
-    uint32_t sa = wave_incl_scan(a), sb = wave_incl_scan(term);
-    uint32_t A = (1u + rdlane(sa, 63)) % 65521u;
-    uint32_t B = (uint32_t)(((uint64_t)rdlane(sb, 63) + (uint64_t)(n % 65521u)) % 65521u);
-    return (B << 16) | A;
-}
 
 // zlib / gzip header (RFC 1950 sec. 2.2, RFC 1952 sec. 2.3), checks in zlib's order.  Returns
 // ST_RUNNING and the header length in bytes, or the final status (need-input / error / need-dict).

@@ -124,6 +124,8 @@ const char *chip_decoder_strerror(int format, int32_t code);
  *   status[i]   CHIP_FINISHED / CHIP_NEED_INPUT (stream truncated) / CHIP_NEED_OUTPUT (out_cap too
  *               small) / CHIP_NEED_DICT, or a negative codec error with the meaning of DecodeError
  *               (zlib: -3 data error; zstd: -(ZSTD_ErrorCode), e.g. -20 corruption, -22 checksum)
+ * For CHIP_FMT_ZSTD: on CHIP_NEED_OUTPUT out_len counts whole blocks only, and the unit's range up to
+ * out_cap[i] may be used as scratch (regenerated literals are parked at its end while a block decodes).
  * in_base must be 4-byte aligned and its allocation padded to a multiple of 4 bytes.
  * `format` is one CHIP_FMT_* for the whole batch.  `stream` is a hipStream_t (NULL = default
  * stream); the call only enqueues work.  Returns CHIP_OK or a CHIP_E_* code.
@@ -162,7 +164,9 @@ chip_encoder *chip_encoder_reset(chip_encoder *e);
 void chip_encoder_free(chip_encoder *e);
 
 /* Batched level-1 encode of n independent units (device pointers, one wavefront per unit).
- * out_len[i] = compressed size; status[i] = CHIP_ENC_FINISHED or CHIP_ENC_NEED_OUTPUT. */
+ * out_len[i] = compressed size; status[i] = CHIP_ENC_FINISHED or CHIP_ENC_NEED_OUTPUT.  Each unit becomes
+ * one complete stream of `format` (wrapper, one fixed-Huffman or stored deflate body, trailer).  The
+ * range out_off[i] .. +out_cap[i] may be used as scratch beyond out_len[i]. */
 int chip_encode_batch(int format, int level, size_t n, const void *in_base, const uint64_t *in_off,
                       const uint32_t *in_len, void *out_base, const uint64_t *out_off, const uint32_t *out_cap,
                       uint32_t *out_len, int32_t *status, void *stream);
