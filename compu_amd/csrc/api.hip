@@ -131,6 +131,10 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     case CHIP_FMT_GZIP:
     case CHIP_FMT_AUTO: e = launch_inflate(a, (hipStream_t)stream); break;
     case CHIP_FMT_ZSTD: e = launch_zstd_decode(a, 0, (hipStream_t)stream); break;
+    case CHIP_FMT_DETECT:  // both kernels see every unit; each takes the ones Detection::detect assigns to it
+        e = launch_inflate(a, (hipStream_t)stream);
+        if (e == hipSuccess) e = launch_zstd_decode(a, 0, (hipStream_t)stream);
+        break;
     default: return CHIP_E_INVALID;
     }
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;

@@ -47,6 +47,23 @@ hipError_t launch_detect(size_t n, const uint8_t *in_base, const uint64_t *in_of
 hipError_t launch_deflate_l1(const BatchArgs &a, int level, uint32_t flags, uint32_t check_seed, uint64_t total_before,
                              uint32_t *check_out, hipStream_t stream);
 
+// Detection::detect (src/decoder/mod.rs:28-114) on device: first 2-4 bytes of a unit -> CHIP_DETECT_*.
+// The FLG table of mod.rs:44-55 is packed one word per CINFO; the 0x68 row never matches in the
+// reference (mod.rs:80-82 lacks the `return`) and is kept that way.
+__device__ __forceinline__ int32_t detect_kind(const uint8_t *b, uint32_t len)
+{
+    if (len < 2) return CHIP_DETECT_NONE;
+    const uint32_t b0 = b[0], b1 = b[1];
+    if (b0 == 0x1f && b1 == 0x8b) return CHIP_DETECT_GZIP;
+    if (((b0 << 8) | b1) % 31 == 0 && (b0 & 0x8f) == 0x08 && b0 != 0x68) {
+        const uint32_t rows[8] = {0x1d5b99d7u, 0x195795d3u, 0x155391cfu, 0x114f8dcbu, 0x0d4b89c7u, 0x094785c3u, 0x054381deu, 0x015e9cdau};
+        const uint32_t r = rows[b0 >> 4];
+        if (b1 == (r >> 24) || b1 == ((r >> 16) & 0xff) || b1 == ((r >> 8) & 0xff) || b1 == (r & 0xff)) return CHIP_DETECT_ZLIB;
+    }
+    if (len < 4) return CHIP_DETECT_NONE;
+    return (b0 == 0x28 && b1 == 0xb5 && b[2] == 0x2f && b[3] == 0xfd) ? CHIP_DETECT_ZSTD : CHIP_DETECT_UNKNOWN;
+}
+
 // ---- wavefront helpers (wave = 64 lanes, one wave per workgroup in the codec kernels) ----------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }

@@ -774,9 +774,23 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
     STAT_DECL;
     STAT_T0();
     uint32_t wrap = 0;
-    if (a.format != CHIP_FMT_DEFLATE) {
+    int32_t format = a.format;
+    if (format == CHIP_FMT_DETECT) {
+        const int32_t kind = detect_kind(gin, in_len);
+        if (kind == CHIP_DETECT_ZSTD) return;  // the zstd kernel of the same batch call owns this unit
+        if (kind == CHIP_DETECT_GZIP || kind == CHIP_DETECT_ZLIB) format = CHIP_FMT_AUTO;
+        else {
+            if (lane == 0) {
+                a.out_len[u] = 0;
+                a.in_used[u] = 0;
+                a.status[u] = kind == CHIP_DETECT_NONE ? CHIP_NEED_INPUT : CHIP_UNKNOWN_FORMAT;
+            }
+            return;
+        }
+    }
+    if (format != CHIP_FMT_DEFLATE) {
         uint32_t hdr = 0;
-        status = parse_wrapper(L.lit_lut, gin, in_len, a.format, wrap, hdr);
+        status = parse_wrapper(L.lit_lut, gin, in_len, format, wrap, hdr);
         pos += hdr * 8u;
     }
     if (status == ST_RUNNING) win_load(L, w, pos >> 5);

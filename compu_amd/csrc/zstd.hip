@@ -402,6 +402,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
     const uint32_t in_len = a.in_len[u];
     uint8_t *gout = a.out_base + a.out_off[u];
     const uint32_t cap = a.out_cap[u];
+    if (a.format == CHIP_FMT_DETECT && detect_kind(gin, in_len) != CHIP_DETECT_ZSTD) return;  // the inflate kernel's unit
 
     Bits b;
     const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);

@@ -27,6 +27,9 @@ enum { CHIP_NEED_INPUT = 0, CHIP_NEED_OUTPUT = 1, CHIP_FINISHED = 2 };
  * by CHIP_FINISHED in the per-unit status array, hence a code of its own.  chip_decode() reports
  * it as err = 2 like the reference. */
 enum { CHIP_NEED_DICT = 3 };
+/* Batch status only, CHIP_FMT_DETECT: the unit is neither gzip, zlib nor zstd (Detection::Unknown);
+ * a unit too short to classify (detect() == None) reports CHIP_NEED_INPUT. */
+enum { CHIP_UNKNOWN_FORMAT = 4 };
 
 /* encoder::EncodeOp src/encoder/mod.rs:12-23, encoder::EncodeStatus src/encoder/mod.rs:27-38 */
 enum { CHIP_OP_PROCESS = 0, CHIP_OP_FLUSH = 1, CHIP_OP_FINISH = 2 };
@@ -39,7 +42,10 @@ enum {
     CHIP_FMT_ZLIB = 15,
     CHIP_FMT_GZIP = 31,
     CHIP_FMT_AUTO = 47, /* decoder only: zlib or gzip, src/decoder/zlib_common.rs:11-14 */
-    CHIP_FMT_ZSTD = 100
+    CHIP_FMT_ZSTD = 100,
+    /* chip_decode_batch only: route every unit by Detection::detect (src/decoder/mod.rs:28-114) to the
+     * zlib/gzip or the zstd decoder -- the mixed gzip+zstd batch of BASELINE.json configs[4] */
+    CHIP_FMT_DETECT = 0
 };
 
 /* decoder::Detection src/decoder/mod.rs:9-21; CHIP_DETECT_NONE is Rust's `None` (too few bytes) */

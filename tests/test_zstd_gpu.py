@@ -116,3 +116,48 @@ def test_truncated_and_corrupt_frames_match_oracle(gpu, alice):
             assert outs[i] == r_out, (i, len(outs[i]), len(r_out))
         if r_st == 2:
             assert iu[i] == r_used
+
+
+def test_mixed_gzip_zstd_batch_routed_by_detection(gpu, alice):
+    """BASELINE.json configs[4] in small: a batch of gzip, zlib and zstd units routed per unit by
+    Detection::detect (src/decoder/mod.rs:28-114); unknown units are reported, not decoded."""
+    import zlib
+
+    import compu_amd
+
+    z = zstd_ref.load()
+    rnd = random.Random(77)
+    datas, parts, kinds = [], [], []
+    for it in range(300):
+        n = rnd.choice([0, 10, 1000, 65536])
+        data = _mk(rnd.randrange(5), n, rnd, alice)
+        k = rnd.randrange(5)
+        if k == 0:
+            comp = zstd_ref.compress(z, data, 3, True, True)
+        elif k == 1:
+            co = zlib.compressobj(6, zlib.DEFLATED, 31)
+            comp = co.compress(data) + co.flush()
+        elif k == 2:
+            comp = zlib.compress(data, 6)  # 78 9c
+        elif k == 3:
+            co = zlib.compressobj(6, zlib.DEFLATED, 13)  # CINFO 5 -> 58 85: a zlib header the reference's table knows
+            comp = co.compress(data) + co.flush()
+        else:
+            comp = b"PK\x03\x04 not a known stream"
+        datas.append(data)
+        parts.append(comp)
+        kinds.append(k)
+    outs, ol, iu, st = run_batch(gpu, 0, parts, [max(len(d), 1) for d in datas], check_tail=False)
+    for i, k in enumerate(kinds):
+        assert compu_amd.Detection.detect(parts[i]) == [compu_amd.Detection.Zstd, compu_amd.Detection.Gzip, compu_amd.Detection.Zlib,
+                                                        compu_amd.Detection.Zlib, compu_amd.Detection.Unknown][k]
+        if k == 4:
+            assert st[i] == 4 and ol[i] == 0  # CHIP_UNKNOWN_FORMAT
+        else:
+            assert st[i] == 2 and outs[i] == datas[i] and iu[i] == len(parts[i]), (i, k, st[i])
+    # the 0x68 quirk of the reference table (mod.rs:80-82): a valid `68 81` zlib stream is Unknown to the router
+    co = zlib.compressobj(6, zlib.DEFLATED, 14)
+    q = co.compress(b"quirk") + co.flush()
+    assert q[:2] == b"\x68\x81" and compu_amd.Detection.detect(q) == compu_amd.Detection.Unknown
+    outs, ol, iu, st = run_batch(gpu, 0, [q], [16], check_tail=False)
+    assert st[0] == 4
