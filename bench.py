@@ -35,16 +35,71 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def make_workload(kind, payload, n_units, threads):
+def make_workload(kind, payload, n_units, threads, first_unit=0):
     from bench_support import synth
 
     t0 = time.time()
-    packed, offs, lens = synth.deflate_units(payload, n_units, kind=kind, threads=threads)
+    if kind == "mixed":
+        packed, offs, lens = synth.mixed_units(payload, n_units, first_unit=first_unit, threads=threads)
+    else:
+        packed, offs, lens = synth.deflate_units(payload, n_units, kind=kind, threads=threads)
     log(f"[bench] compressed {n_units} units as '{kind}' in {time.time() - t0:.1f}s, ratio {lens.sum() / (n_units * UNIT):.3f}")
     return packed, offs, lens
 
 
-def run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps, warmup, dist, verify=True):
+def run_encode(torch, compu_amd, payload_dev, n_units, steps, warmup, dist):
+    """BASELINE.json configs[3]: level-1 encode of every unit (raw deflate), verified by inflating it again on the GPU."""
+    dev = payload_dev.device
+    cap = compu_amd.encode_bound(-15, UNIT)
+    cap = (cap + 15) & ~15
+    d_in_off = torch.arange(n_units, dtype=torch.int64, device=dev) * UNIT
+    d_in_len = torch.full((n_units,), UNIT, dtype=torch.int32, device=dev)
+    d_out = torch.empty(n_units * cap, dtype=torch.uint8, device=dev)
+    d_out_off = torch.arange(n_units, dtype=torch.int64, device=dev) * cap
+    d_out_cap = torch.full((n_units,), cap, dtype=torch.int32, device=dev)
+    d_out_len = torch.empty(n_units, dtype=torch.int32, device=dev)
+    d_status = torch.empty(n_units, dtype=torch.int32, device=dev)
+
+    def step():
+        compu_amd.encode_batch(-15, 1, payload_dev, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step()
+        b.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    # verify: inflate the compressed units again and compare with the payload
+    back = torch.empty_like(payload_dev)
+    ol, iu, st = compu_amd.decode_batch(-15, d_out, d_out_off, d_out_len, back, d_in_off, d_in_len)
+    torch.cuda.synchronize()
+    ok = bool((d_status == 2).all().item()) and bool((st == 2).all().item()) and bool(torch.equal(back, payload_dev))
+    return {
+        "elapsed_s": elapsed,
+        "kernel_ms_avg": float(np.mean(kernel_ms)),
+        "kernel_ms_min": float(np.min(kernel_ms)),
+        "comp_bytes": int(d_out_len.to(torch.int64).sum().item()),
+        "out_bytes": n_units * UNIT,
+        "verified": ok,
+    }
+
+
+def run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps, warmup, dist, verify=True, fmt=-15):
     dev = torch.device("cuda", torch.cuda.current_device())
     d_in = torch.from_numpy(packed).to(dev)
     d_in_off = torch.from_numpy(offs.astype(np.int64)).to(dev)
@@ -57,7 +112,7 @@ def run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps,
     d_status = torch.empty(n_units, dtype=torch.int32, device=dev)
 
     def step():
-        compu_amd.decode_batch(-15, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_in_used, d_status)
+        compu_amd.decode_batch(fmt, d_in, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_in_used, d_status)
 
     for _ in range(warmup):
         step()
@@ -125,9 +180,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--units", type=int, default=65536, help="units per GPU")
-    ap.add_argument("--workload", default="dynamic", choices=["dynamic", "fixed", "stored", "level1"])
+    ap.add_argument("--workload", default="dynamic", choices=["dynamic", "fixed", "stored", "level1", "mixed", "encode"])
     ap.add_argument("--extra", type=int, default=1, help="also measure the configs[1] variants (stored, fixed)")
-    ap.add_argument("--cpu-sample", type=int, default=8192)
+    ap.add_argument("--cpu-sample", type=int, default=65536, help="units the CPU baseline decodes (about 10-30 s of CPU work in total)")
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -151,11 +206,13 @@ def main():
         dist = dist_mod
     compu_amd.lib().chip_set_device(local_rank)
 
-    n_units = args.units
+    from compu_amd import shard
+
+    first_unit, n_units = shard.weak_shard(args.units, rank)
     ncpu = os.cpu_count() or 1
     threads = max(1, min(32, ncpu // max(1, min(world, 8))))
     t0 = time.time()
-    payload = synth.payloads(n_units, first_unit=rank * n_units, threads=threads)
+    payload = synth.payloads(n_units, first_unit=first_unit, threads=threads)
     log(f"[bench] rank {rank}: generated {n_units} x 64 KiB payload units in {time.time() - t0:.1f}s ({threads} threads)")
     d_expect = torch.from_numpy(payload).to(torch.device("cuda", local_rank))
 
@@ -165,13 +222,19 @@ def main():
     results = {}
     cpu = None
     for kind in kinds:
-        packed, offs, lens = make_workload(kind, payload, n_units, threads)
         steps = args.steps if kind == args.workload else max(3, min(args.steps, 5))
-        res = run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps, args.warmup, dist)
+        if kind == "encode":
+            res = run_encode(torch, compu_amd, d_expect, n_units, steps, args.warmup, dist)
+            res["steps"] = steps
+            results[kind] = res
+            log(f"[bench] encode: kernel {res['kernel_ms_avg']:.3f} ms avg, ratio {res['comp_bytes'] / res['out_bytes']:.3f}, verified={res['verified']}")
+            continue
+        packed, offs, lens = make_workload(kind, payload, n_units, threads, first_unit)
+        res = run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps, args.warmup, dist, fmt=0 if kind == "mixed" else -15)
         res["steps"] = steps
         results[kind] = res
         log(f"[bench] {kind}: kernel {res['kernel_ms_avg']:.3f} ms avg, verified={res['verified']}")
-        if kind == args.workload and rank == 0 and world == 1 and not args.no_cpu:
+        if kind == args.workload and kind != "mixed" and rank == 0 and world == 1 and not args.no_cpu:
             cpu = cpu_baseline(packed, offs, lens, args.cpu_sample, threads=ncpu)
         del packed
 
@@ -181,14 +244,15 @@ def main():
         return
 
     main_res = results[args.workload]
-    total_out = main_res["out_bytes"] * world
-    value = total_out * main_res["steps"] / main_res["elapsed_s"] / 1e9
+    value = shard.aggregate_rate(main_res["out_bytes"], world, main_res["steps"], main_res["elapsed_s"]) / 1e9
     ach = (main_res["comp_bytes"] + main_res["out_bytes"]) / (main_res["kernel_ms_avg"] * 1e-3) / 1e9
     names = {
         "dynamic": "cfg2: raw-deflate units, 64 KiB payload each, zlib L6 dynamic-Huffman + LZ77, ratio~0.5",
         "fixed": "cfg1: raw-deflate units, 64 KiB payload each, zlib L6 Z_FIXED (fixed Huffman + LZ77)",
         "stored": "cfg1: raw-deflate units, 64 KiB payload each, stored blocks (level 0)",
         "level1": "raw-deflate units, 64 KiB payload each, zlib L1",
+        "mixed": "cfg4: 64 KiB payload units, gzip (zlib L6) or zstd (L3, checksum) by splitmix64(unit index), routed by Detection",
+        "encode": "cfg3: level-1 class DEFLATE encode of 64 KiB units (greedy 32 KiB-window match + fixed Huffman)",
     }
     line = {
         "metric": METRIC,
@@ -208,14 +272,14 @@ def main():
             "units_per_gpu": n_units,
             "unit_payload_bytes": UNIT,
             "compressed_ratio": round(main_res["comp_bytes"] / main_res["out_bytes"], 4),
-            "format": "raw deflate (ZlibMode::Deflate)",
+            "format": {"mixed": "gzip + zstd, CHIP_FMT_DETECT", "encode": "raw deflate out"}.get(args.workload, "raw deflate (ZlibMode::Deflate)"),
             "sharding": f"units by index over {world} GPU(s), no collective",
         },
         "hbm_peak_frac_decompressed": round(value / (HBM_PEAK_GBPS * world), 5),
         "verified_bit_exact": bool(all(r["verified"] for r in results.values())),
         "roofline": {
             "bound": "hbm",
-            "kernel": "chip::inflate_kernel",
+            "kernel": {"mixed": "chip::inflate_kernel + chip::zstd_kernel", "encode": "chip::deflate_kernel"}.get(args.workload, "chip::inflate_kernel"),
             "achieved": round(ach, 3),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

@@ -79,3 +79,66 @@ def deflate_units(payload, n_units, unit_size=UNIT, kind="dynamic", wbits=-15, t
     packed = np.zeros((total + 3) & ~3, np.uint8)
     packed[:total] = np.frombuffer(b"".join(parts), dtype=np.uint8)
     return packed, offs, lens
+
+
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+_zstd = None
+
+
+def _zstd_lib():
+    global _zstd
+    if _zstd is None:
+        z = C.CDLL("libzstd.so.1")
+        z.ZSTD_compressBound.restype = C.c_size_t
+        z.ZSTD_compressBound.argtypes = [C.c_size_t]
+        z.ZSTD_createCCtx.restype = C.c_void_p
+        z.ZSTD_freeCCtx.argtypes = [C.c_void_p]
+        z.ZSTD_CCtx_setParameter.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        z.ZSTD_compress2.restype = C.c_size_t
+        z.ZSTD_compress2.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        z.ZSTD_isError.argtypes = [C.c_size_t]
+        _zstd = z
+    return _zstd
+
+
+def _mixed_one(args):
+    data, unit_index = args
+    if _splitmix64(unit_index) & 1:
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)  # gzip, no name
+        return co.compress(data) + co.flush()
+    z = _zstd_lib()
+    arr = np.frombuffer(data, dtype=np.uint8)
+    cctx = z.ZSTD_createCCtx()
+    z.ZSTD_CCtx_setParameter(cctx, 100, 3)  # level 3
+    z.ZSTD_CCtx_setParameter(cctx, 201, 1)  # content checksum
+    cap = z.ZSTD_compressBound(arr.size)
+    dst = np.empty(cap, np.uint8)
+    n = z.ZSTD_compress2(cctx, dst.ctypes.data, cap, arr.ctypes.data, arr.size)
+    z.ZSTD_freeCCtx(cctx)
+    assert not z.ZSTD_isError(n)
+    return dst[:n].tobytes()
+
+
+def mixed_units(payload, n_units, first_unit=0, unit_size=UNIT, threads=None):
+    """BASELINE.json configs[4]: unit i is a gzip member (zlib level 6) if splitmix64(i) is odd, else a
+    zstd frame (level 3, single block, with checksum).  Returns (packed, offsets, lengths)."""
+    threads = threads or min(32, os.cpu_count() or 1)
+    mv = memoryview(payload)
+    jobs = [(mv[i * unit_size : (i + 1) * unit_size], first_unit + i) for i in range(n_units)]
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(_mixed_one, jobs, chunksize=64))
+    lens = np.array([len(p) for p in parts], dtype=np.uint32)
+    offs = np.zeros(n_units, dtype=np.uint64)
+    if n_units > 1:
+        offs[1:] = np.cumsum(lens[:-1], dtype=np.uint64)
+    total = int(lens.sum())
+    packed = np.zeros((total + 3) & ~3, np.uint8)
+    packed[:total] = np.frombuffer(b"".join(parts), dtype=np.uint8)
+    return packed, offs, lens

@@ -1,0 +1,61 @@
+"""The C ABI: every symbol include/compu_hip.h declares is exported by the built library (no GPU needed),
+Detection::detect on the host, and -- on the GPU box -- the C++ replay of the reference's tests."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "compu_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(chip_[a-z0-9_]+)\s*\(", text)) - {"chip_malloc_fn", "chip_free_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    import compu_amd
+
+    lib = compu_amd.lib()
+    names = _declared_symbols()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/compu_hip.h but not exported"
+    assert lib.chip_version().startswith(b"compu-hip")
+    # library-level argument checks need no device
+    assert lib.chip_decode_batch(12345, 1, None, None, None, None, None, None, None, None, None, None) == -101
+    assert lib.chip_encode_bound(31, 65536) >= 65536 + 18
+
+
+def test_detection_table_matches_reference():
+    """src/decoder/mod.rs:28-114 incl. the None cases (:97-104) and the 0x68 quirk (:80-82)"""
+    import compu_amd
+    from compu_amd import Detection
+
+    assert Detection.detect(b"") is None and Detection.detect(b"\x1f") is None
+    assert Detection.detect(b"\x1f\x8b") == Detection.Gzip
+    assert Detection.detect(b"\x28\xb5\x2f") is None  # 3 bytes: not enough for the zstd magic
+    assert Detection.detect(b"\x28\xb5\x2f\xfd") == Detection.Zstd
+    assert Detection.detect(b"abcd") == Detection.Unknown and Detection.detect(b"ab") is None
+    table = {0x08: (0x1D, 0x5B, 0x99, 0xD7), 0x18: (0x19, 0x57, 0x95, 0xD3), 0x28: (0x15, 0x53, 0x91, 0xCF), 0x38: (0x11, 0x4F, 0x8D, 0xCB),
+             0x48: (0x0D, 0x4B, 0x89, 0xC7), 0x58: (0x09, 0x47, 0x85, 0xC3), 0x78: (0x01, 0x5E, 0x9C, 0xDA)}
+    for cmf, flgs in table.items():
+        for flg in flgs:
+            assert Detection.detect(bytes([cmf, flg])) == Detection.Zlib
+    for flg in (0x05, 0x43, 0x81, 0xDE):  # the 0x68 arm falls through in the reference
+        assert Detection.detect(bytes([0x68, flg])) is None
+        assert Detection.detect(bytes([0x68, flg, 0, 0])) == Detection.Unknown
+    assert Detection.detect(b"\x78\x9d") is None  # right CMF, FLG not in the table
+
+
+@pytest.mark.gpu
+def test_cpp_replay_of_reference_tests():
+    exe = os.path.join(ROOT, "tests", "cpp", "test_reference")
+    if not os.path.exists(exe):
+        subprocess.check_call(["bash", os.path.join(ROOT, "compu_amd", "csrc", "build.sh")])
+    out = subprocess.run([exe, os.path.join(ROOT, "tests", "golden")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "test result: ok" in out.stdout
