@@ -198,14 +198,15 @@ def xxh64(data, seed=0):
     return lib().orc_xxh64(_ptr(a), len(data), seed)
 
 
-def _units(fn, mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads):
+def _units(fn, mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads, out=None):
     n = len(in_len)
     in_buf = np.ascontiguousarray(in_buf, dtype=np.uint8)
     in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
     in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
     out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
     out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
-    out = np.zeros(max(int(out_cap_total), 1), np.uint8)
+    if out is None:
+        out = np.zeros(max(int(out_cap_total), 1), np.uint8)
     out_len = np.zeros(n, np.uint32)
     status = np.zeros(n, np.int32)
     args = [n, _ptr(in_buf), _ptr(in_off), _ptr(in_len), _ptr(out), _ptr(out_off), _ptr(out_cap), _ptr(out_len), _ptr(status), threads]
@@ -213,9 +214,9 @@ def _units(fn, mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, th
     return out, out_len, status, bad
 
 
-def inflate_units(mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads=1):
+def inflate_units(mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads=1, out=None):
     """Batch form of the compu CPU loop (one decoder per worker, reset per unit)."""
-    return _units(lib().orc_inflate_units, mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads)
+    return _units(lib().orc_inflate_units, mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads, out)
 
 
 def zstd_units(in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads=1):
