@@ -31,6 +31,27 @@ UNIT = 65536
 METRIC = "decompressed GB/s (whole node), batched 64 KiB DEFLATE blocks; % HBM peak"
 
 
+def usable_cpus():
+    """CPUs this process may really use: affinity mask capped by the cgroup CPU quota (the GPU box gives a
+    one-GPU job a share of the host, os.cpu_count() reports the whole host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / period + 0.5)))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
@@ -210,7 +231,7 @@ def main():
     from compu_amd import shard
 
     first_unit, n_units = shard.weak_shard(args.units, rank)
-    ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
     threads = max(1, min(32, ncpu // max(1, min(world, 8))))
     t0 = time.time()
     payload = synth.payloads(n_units, first_unit=first_unit, threads=threads)

@@ -53,10 +53,13 @@ constexpr int CL_ROOT = 7;
 // where the two decodes fall into step (the merge) can be proven.  S_BITS is an odd number of
 // dwords so that the 64 lanes' window reads hit distinct LDS banks.
 #ifndef CHIP_S_BITS
-#define CHIP_S_BITS 288
-#define CHIP_O_BITS 256
-#define CHIP_TOK_CAP 2304
-#define CHIP_FIX_ROUNDS 3
+// measured on MI355X (round 1): 160/160 bits with a 1024-token buffer keeps LDS at 13.9 KB per wave
+// (11 waves per CU) and beats larger super-rounds, whose per-round overheads are lower but whose
+// occupancy is 7-8 waves per CU
+#define CHIP_S_BITS 160
+#define CHIP_O_BITS 160
+#define CHIP_TOK_CAP 1024
+#define CHIP_FIX_ROUNDS 5
 #endif
 constexpr int S_BITS = CHIP_S_BITS;
 constexpr int O_BITS = CHIP_O_BITS;
@@ -84,12 +87,17 @@ struct alignas(16) WaveLds {
     uint32_t lit_sorted[288];
     uint32_t dist_sorted[32];
     uint32_t inbuf[IN_DW];
-    uint32_t tok[TOK_CAP + 192];  // tokens (and pass-1 bitmaps), then 192 words of copy-phase scratch
-    uint32_t cl_lut[1 << CL_ROOT];
-    uint32_t cl_sorted[20];
-    HuffMeta lit_h, dist_h, cl_h;
-    uint32_t count[16];
-    uint8_t lens[320];
+    union {
+        uint32_t tok[TOK_CAP + 192];  // tokens (and pass-1 bitmaps), then 192 words of copy-phase scratch
+        struct {                      // block-header scratch: only live while no tokens are buffered
+            uint32_t cl_lut[1 << CL_ROOT];
+            uint32_t cl_sorted[20];
+            HuffMeta cl_h;
+            uint32_t count[16];
+            uint8_t lens[320];
+        } hdr;
+    };
+    HuffMeta lit_h, dist_h;
 };
 
 // RFC 1951 sec. 3.2.5, closed forms of the base/extra tables
@@ -165,18 +173,18 @@ __device__ int build_table(WaveLds &L, const uint8_t *lens, int n, int type, int
                            HuffMeta &H)
 {
     const uint32_t lane = lane_id();
-    if (lane < 16) L.count[lane] = 0;
+    if (lane < 16) L.hdr.count[lane] = 0;
     WSYNC();
     for (int s = lane; s < n; s += 64) {
         uint32_t l = lens[s];
-        if (l) atomicAdd(&L.count[l], 1u);
+        if (l) atomicAdd(&L.hdr.count[l], 1u);
     }
     WSYNC();
     uint32_t code = 0, off = 0, maxlen = 0, mynext = 0;
     int left = 1;
     bool over = false;
     for (uint32_t l = 1; l <= 15; l++) {
-        uint32_t c = L.count[l];
+        uint32_t c = L.hdr.count[l];
         if (c) maxlen = l;
         left = (left << 1) - (int)c;
         if (left < 0) over = true;
@@ -425,9 +433,14 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
         } else {
             total = rdlane(incl, 63u);
         }
+#ifndef CHIP_EXP_NOLIT
         if (valid && !len && start < cap) gout[start] = (uint8_t)val;
+#endif
         uint32_t mlen = (valid && len) ? len : 0u;
         uint64_t mm = __ballot(mlen != 0);
+#ifdef CHIP_EXP_NOMATCH
+        mm = 0;
+#endif
         STAT_ACC(16);
         if (mm) {
             uint32_t mbi = wave_incl_scan(mlen);  // match bytes up to and including this match
@@ -498,11 +511,18 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
                 STAT_ACC(18);
                 // software pipeline: this step's loads go out before the previous step's stores unless
                 // this step reads bytes the previous one writes
+#ifdef CHIP_EXP_NOMEM
+                uint8_t bytes[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) bytes[j] = (uint8_t)(srcs[j] ^ dsts[j]);
+                if (nbytes == 0xdeadbeef) drain_copy(pc, gout, cap);
+#else
                 if (pc.valid && __any(mine && srcend > pc.d0)) drain_copy(pc, gout, cap);
                 uint8_t bytes[4];
 #pragma unroll
                 for (int j = 0; j < 4; j++) bytes[j] = gout[has[j] ? srcs[j] : 0u];  // lanes without a byte re-read byte 0
                 drain_copy(pc, gout, cap);
+#endif
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     pc.dst[j] = dsts[j];
@@ -845,12 +865,12 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
         }
         if (type == 1) {
             if (tables != 1) {
-                for (uint32_t s = lane; s < 288; s += 64) L.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+                for (uint32_t s = lane; s < 288; s += 64) L.hdr.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
                 WSYNC();
-                build_table(L, L.lens, 288, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h);
-                if (lane < 32) L.lens[lane] = 5;
+                build_table(L, L.hdr.lens, 288, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h);
+                if (lane < 32) L.hdr.lens[lane] = 5;
                 WSYNC();
-                build_table(L, L.lens, 32, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h);
+                build_table(L, L.hdr.lens, 32, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h);
                 tables = 1;
             }
         } else {
@@ -873,17 +893,17 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                 break;
             }
             win_ensure(L, w, pos, 128);
-            if (lane < 19) L.lens[lane] = 0;
+            if (lane < 19) L.hdr.lens[lane] = 0;
             WSYNC();
             if (lane < ncode) {
                 static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
                 uint32_t l2, h2;
                 win_bits(L, w, pos + 3 * lane, l2, h2);
-                L.lens[order[lane]] = (uint8_t)(l2 & 7u);
+                L.hdr.lens[order[lane]] = (uint8_t)(l2 & 7u);
             }
             WSYNC();
             pos += 3 * ncode;
-            if (build_table(L, L.lens, 19, T_CODES, CL_ROOT, L.cl_lut, L.cl_sorted, L.cl_h)) {
+            if (build_table(L, L.hdr.lens, 19, T_CODES, CL_ROOT, L.hdr.cl_lut, L.hdr.cl_sorted, L.hdr.cl_h)) {
                 status = Z_DATA_ERROR;
                 break;
             }
@@ -892,14 +912,14 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
             while (have < total) {
                 win_ensure(L, w, pos);
                 win_bits(L, w, pos, lo, hi);
-                uint32_t e = L.cl_lut[lo & 127u];
+                uint32_t e = L.hdr.cl_lut[lo & 127u];
                 uint32_t cl = e & 15u, sym = e >> 16;
                 if (sym < 16) {
                     if (pos + cl > end_bit) {
                         status = CHIP_NEED_INPUT;
                         break;
                     }
-                    if (lane == 0) L.lens[have] = (uint8_t)sym;
+                    if (lane == 0) L.hdr.lens[have] = (uint8_t)sym;
                     prev = sym;
                     have++;
                     pos += cl;
@@ -925,18 +945,18 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                     status = Z_DATA_ERROR;
                     break;
                 }
-                for (uint32_t j = lane; j < rep; j += 64) L.lens[have + j] = (uint8_t)val;
+                for (uint32_t j = lane; j < rep; j += 64) L.hdr.lens[have + j] = (uint8_t)val;
                 have += rep;
                 pos += cl + eb;
             }
             if (status != ST_RUNNING) break;
             WSYNC();
-            if (L.lens[256] == 0) {
+            if (L.hdr.lens[256] == 0) {
                 status = Z_DATA_ERROR;
                 break;
             }
-            if (build_table(L, L.lens, (int)nlen, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h) ||
-                build_table(L, L.lens + nlen, (int)ndist, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h)) {
+            if (build_table(L, L.hdr.lens, (int)nlen, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h) ||
+                build_table(L, L.hdr.lens + nlen, (int)ndist, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h)) {
                 status = Z_DATA_ERROR;
                 break;
             }

@@ -1,0 +1,26 @@
+"""Timing-only run of a (possibly deliberately broken, experiment) build: COMPU_HIP_LIB=... python tools/time_run.py [kind] [units]"""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import compu_amd
+from bench_support import synth
+kind = sys.argv[1] if len(sys.argv) > 1 else "dynamic"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
+dev = torch.device("cuda:0")
+pay = synth.payloads(n)
+packed, offs, lens = synth.deflate_units(pay, n, kind=kind)
+d_out = torch.zeros(n * 65536, dtype=torch.uint8, device=dev)
+args = (-15, torch.from_numpy(packed).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev),
+        d_out, torch.arange(n, dtype=torch.int64, device=dev) * 65536, torch.full((n,), 65536, dtype=torch.int32, device=dev))
+for _ in range(2):
+    compu_amd.decode_batch(*args)
+torch.cuda.synchronize()
+ts = []
+for _ in range(5):
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); ol, iu, st = compu_amd.decode_batch(*args); b.record(); torch.cuda.synchronize()
+    ts.append(a.elapsed_time(b))
+ok = bool((st == 2).all()) and torch.equal(d_out, torch.from_numpy(pay).to(dev))
+print(f"{os.path.basename(os.environ.get('COMPU_HIP_LIB','prod'))}: {kind} {n} units: {min(ts):.3f} ms (correct={ok})")
