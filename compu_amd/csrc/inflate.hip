@@ -45,20 +45,24 @@ __device__ __forceinline__ constexpr uint32_t mk_entry(uint32_t cl, uint32_t eb,
 }
 enum : int { T_CODES = 0, T_LENS = 1, T_DISTS = 2 };
 
-constexpr int LIT_ROOT = 10;
-constexpr int DIST_ROOT = 9;
+#ifndef CHIP_LIT_ROOT
+#define CHIP_LIT_ROOT 9   // 9/8-bit roots: 3 KB of tables; longer codes take the canonical register path
+#define CHIP_DIST_ROOT 8
+#endif
+constexpr int LIT_ROOT = CHIP_LIT_ROOT;
+constexpr int DIST_ROOT = CHIP_DIST_ROOT;
 constexpr int CL_ROOT = 7;
 // Speculative wave-parallel decode geometry: per super-round lane i owns S_BITS of the stream
 // starting at B + i*S_BITS and decodes O_BITS further into its successor's range so that the point
 // where the two decodes fall into step (the merge) can be proven.  S_BITS is an odd number of
 // dwords so that the 64 lanes' window reads hit distinct LDS banks.
-#ifndef CHIP_S_BITS
-// measured on MI355X (round 1): 160/160 bits with a 1024-token buffer keeps LDS at 13.9 KB per wave
-// (11 waves per CU) and beats larger super-rounds, whose per-round overheads are lower but whose
-// occupancy is 7-8 waves per CU
+#ifndef CHIP_S_BITS  // geometry overridable for experiments
+// measured on MI355X (round 1): 160/160 bits, an 864-token buffer and 9/8-bit root tables keep LDS at
+// 10.2 KB per wave (16 waves per CU = 4 per SIMD); larger super-rounds and tables have lower per-round
+// overheads and fewer long-code lookups but run at 7-11 waves per CU and lose
 #define CHIP_S_BITS 160
 #define CHIP_O_BITS 160
-#define CHIP_TOK_CAP 1024
+#define CHIP_TOK_CAP 864
 #define CHIP_FIX_ROUNDS 5
 #endif
 constexpr int S_BITS = CHIP_S_BITS;
