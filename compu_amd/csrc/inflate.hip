@@ -102,6 +102,7 @@ struct alignas(16) WaveLds {
         } hdr;
     };
     HuffMeta lit_h, dist_h;
+    uint32_t use_sub;  // long codes resolve through sub-tables living in lit_sorted/dist_sorted
 };
 
 // RFC 1951 sec. 3.2.5, closed forms of the base/extra tables
@@ -237,6 +238,57 @@ __device__ int build_table(WaveLds &L, const uint8_t *lens, int n, int type, int
     }
     WSYNC();
     return 0;
+}
+
+
+// ---- second-level tables for codes longer than the root ---------------------------------------------
+// A root entry whose code is longer than ROOT carries {cl = 0, [7:4] sub-table index bits, [31:16]
+// offset}; the sub-table entry for the next `bits` stream bits holds the final entry.  Sub-tables are
+// built in scratch and then take the place of sorted[] (lit_sorted + dist_sorted = 320 entries), which
+// is dead once they exist; if a code needs more than 320 sub-entries (possible in theory, not seen) the
+// block keeps sorted[] and decodes long codes canonically instead.
+constexpr uint32_t SUB_CAP = 320;
+
+// Lay out and build the sub-tables of one alphabet into scratch[base ..]; rewrites the long root
+// entries.  Returns the number of sub-entries used, or 0xffffffff when `base + n` would exceed SUB_CAP.
+template <int ROOT>
+__device__ uint32_t build_subtables(const HuffMeta &H, const uint32_t *sorted, uint32_t *lut, uint32_t *scratch, uint32_t base)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t lim_r = rdfirst(H.limit15[ROOT]), top = rdfirst(H.limit15[15]), maxlen = rdfirst(H.maxlen);
+    if (top <= lim_r) return 0;  // no code is longer than the root
+    constexpr uint32_t P = 1u << (15 - ROOT);
+    const uint32_t np = (top - lim_r + P - 1) / P;  // root prefixes that hold long codes
+    uint32_t used = 0;
+    for (uint32_t j0 = 0; j0 < np; j0 += 64) {
+        const uint32_t j = j0 + lane;
+        const bool have = j < np;
+        const uint32_t xj = lim_r + j * P;
+        uint32_t sb = 0;
+        if (have) {
+            // the longest code of a prefix is its last one (canonical order is by length)
+            uint32_t xe = xj + P < top ? xj + P - 1 : top - 1;
+            uint32_t l = 1;
+#pragma unroll
+            for (int k = 1; k < 15; k++) l += (xe >= H.limit15[k]) ? 1u : 0u;
+            sb = l - ROOT;
+        }
+        const uint32_t size = have ? (1u << sb) : 0u;
+        const uint32_t incl = wave_incl_scan(size);
+        const uint32_t off = base + used + incl - size;
+        const uint32_t total = rdlane(incl, 63);
+        if (base + used + total > SUB_CAP) return 0xffffffffu;
+        if (have) {
+            for (uint32_t t = 0; t < size; t++) {
+                uint32_t x15 = xj + ((__brev(t) >> (32 - sb)) << (15 - ROOT - sb));
+                if (sb == 0) x15 = xj;
+                scratch[off + t] = x15 >= top ? mk_entry(maxlen, 0, K_BAD, 0) : canon_lookup(H, sorted, x15);
+            }
+            lut[__brev(xj >> (15 - ROOT)) >> (32 - ROOT)] = (sb << 4) | (off << 16);  // cl = 0: long
+        }
+        used += total;
+    }
+    return used;
 }
 
 struct InWin {
@@ -560,18 +612,27 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
 
 // total bits of the token starting at `pos` (pass 1: boundaries only).  End-of-block and invalid
 // codes count as their code length so that a lane decoding from a guessed start just keeps going.
+// resolve a root entry that marks a code longer than the root table
+template <int ROOT>
+__device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, uint32_t e, uint32_t bits, const LongCodes<ROOT> &lc,
+                                               const uint32_t *sorted)
+{
+    if (use_sub) return L.lit_sorted[(e >> 16) + bfe(bits, ROOT, (e >> 4) & 15u)];
+    return long_lookup<ROOT>(lc, sorted, __brev(bits) >> 17);
+}
+
 __device__ __forceinline__ uint32_t token_bits(const WaveLds &L, const InWin &w, uint32_t pos, const LongCodes<LIT_ROOT> &lcl,
-                                               const LongCodes<DIST_ROOT> &lcd)
+                                               const LongCodes<DIST_ROOT> &lcd, bool use_sub)
 {
     uint32_t lo, hi;
     win_bits(L, w, pos, lo, hi);
     uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-    if ((e & 15u) == 0) e = long_lookup<LIT_ROOT>(lcl, L.lit_sorted, __brev(lo) >> 17);
+    if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
     uint32_t n1 = (e & 15u) + ((e >> 4) & 15u);
     if (((e >> 8) & 3u) == K_LEN) {
         uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
         uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-        if ((e2 & 15u) == 0) e2 = long_lookup<DIST_ROOT>(lcd, L.dist_sorted, __brev(w2) >> 17);
+        if ((e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
         n1 += (e2 & 15u) + ((e2 >> 4) & 15u);
     }
     return n1;
@@ -588,6 +649,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
     const uint32_t lane = lane_id();
     const LongCodes<LIT_ROOT> lcl = load_long_codes<LIT_ROOT>(L.lit_h);
     const LongCodes<DIST_ROOT> lcd = load_long_codes<DIST_ROOT>(L.dist_h);
+    const bool use_sub = rdfirst(L.use_sub) != 0;
     uint32_t *bm = L.tok;  // [word][lane] boundary bitmaps, dead before the tokens are written
     for (;;) {
         const uint32_t B = pos;
@@ -612,7 +674,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
             if (active) {
                 uint32_t rel = p - s;
                 atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-                p += token_bits(L, w, p, lcl, lcd);
+                p += token_bits(L, w, p, lcl, lcd, use_sub);
                 active = p < limit;
             }
         }
@@ -652,7 +714,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
                 if (active) {
                     uint32_t rel = p - s;
                     atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-                    p += token_bits(L, w, p, lcl, lcd);
+                    p += token_bits(L, w, p, lcl, lcd, use_sub);
                     active = p < limit;
                 }
             }
@@ -705,7 +767,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
                 uint32_t lo, hi;
                 win_bits(L, w, p, lo, hi);
                 uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-                if ((e & 15u) == 0) e = long_lookup<LIT_ROOT>(lcl, L.lit_sorted, __brev(lo) >> 17);
+                if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
                 const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
                 uint32_t n1 = cl + eb;
                 uint32_t token = tok_lit(e >> 16);
@@ -713,7 +775,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
                 if (kind == K_LEN) {
                     uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
                     uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-                    if ((e2 & 15u) == 0) e2 = long_lookup<DIST_ROOT>(lcd, L.dist_sorted, __brev(w2) >> 17);
+                    if ((e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
                     const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
                     token = tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2));
                     if (p + n1 + cl2 + eb2 > end_bit) st = LS_NEED_INPUT;
@@ -767,6 +829,25 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         }
         pos = next_B;
     }
+}
+
+
+// After both alphabets are built: try to replace sorted[] by sub-tables (see build_subtables).
+__device__ void finish_tables(WaveLds &L)
+{
+    uint32_t *scratch = &L.tok[512];  // free: no tokens are buffered while tables are built
+    WSYNC();
+    uint32_t n1 = build_subtables<LIT_ROOT>(L.lit_h, L.lit_sorted, L.lit_lut, scratch, 0);
+    uint32_t n2 = n1 == 0xffffffffu ? n1 : build_subtables<DIST_ROOT>(L.dist_h, L.dist_sorted, L.dist_lut, scratch, n1);
+    const bool ok = n1 != 0xffffffffu && n2 != 0xffffffffu;
+    WSYNC();
+    if (ok) {
+        const uint32_t n = n1 + n2;
+        uint32_t *sub = L.lit_sorted;  // lit_sorted[288] and dist_sorted[32] are contiguous: 320 entries
+        for (uint32_t i = lane_id(); i < n; i += 64) sub[i] = scratch[i];
+    }
+    if (lane_id() == 0) L.use_sub = ok ? 1u : 0u;
+    WSYNC();
 }
 
 __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
@@ -875,6 +956,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                 if (lane < 32) L.hdr.lens[lane] = 5;
                 WSYNC();
                 build_table(L, L.hdr.lens, 32, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h);
+                finish_tables(L);
                 tables = 1;
             }
         } else {
@@ -964,6 +1046,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                 status = Z_DATA_ERROR;
                 break;
             }
+            finish_tables(L);
         }
         STAT_ACC(0);
         decode_block(L, w, pos, end_bit, gout, opos, cap, status STAT_ARG);
