@@ -624,18 +624,18 @@ __device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, u
 __device__ __forceinline__ uint32_t token_bits(const WaveLds &L, const InWin &w, uint32_t pos, const LongCodes<LIT_ROOT> &lcl,
                                                const LongCodes<DIST_ROOT> &lcd, bool use_sub)
 {
+    // straight-line on purpose: the distance lookup runs for every lane (a literal lane just ignores it),
+    // which costs no extra issue slots and saves the exec-mask bookkeeping of a divergent branch
     uint32_t lo, hi;
     win_bits(L, w, pos, lo, hi);
     uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
     if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
-    uint32_t n1 = (e & 15u) + ((e >> 4) & 15u);
-    if (((e >> 8) & 3u) == K_LEN) {
-        uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-        uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-        if ((e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
-        n1 += (e2 & 15u) + ((e2 >> 4) & 15u);
-    }
-    return n1;
+    const uint32_t n1 = (e & 15u) + ((e >> 4) & 15u);
+    const bool islen = ((e >> 8) & 3u) == K_LEN;
+    const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+    uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
+    if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
+    return n1 + (islen ? (e2 & 15u) + ((e2 >> 4) & 15u) : 0u);
 }
 
 enum : uint32_t { LS_NONE = 0, LS_EOB = 1, LS_NEED_INPUT = 2, LS_BAD = 3 };
@@ -671,12 +671,11 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         bool active = s < limit;
         while (__any(active)) {
             STAT_ADD(11, 1);
-            if (active) {
-                uint32_t rel = p - s;
-                atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-                p += token_bits(L, w, p, lcl, lcd, use_sub);
-                active = p < limit;
-            }
+            const uint32_t rel = p - s;
+            if (active) atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
+            const uint32_t tb = token_bits(L, w, p, lcl, lcd, use_sub);  // finished lanes idle at their last boundary
+            p += active ? tb : 0u;
+            active = active && p < limit;
         }
         uint32_t e_end = p;  // first boundary at or behind the lane's limit
         WSYNC();
@@ -711,12 +710,11 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
             active = redo;
             while (__any(active)) {
                 STAT_ADD(11, 1);
-                if (active) {
-                    uint32_t rel = p - s;
-                    atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-                    p += token_bits(L, w, p, lcl, lcd, use_sub);
-                    active = p < limit;
-                }
+                const uint32_t rel = p - s;
+                if (active) atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
+                const uint32_t tb = token_bits(L, w, p, lcl, lcd, use_sub);
+                p += active ? tb : 0u;
+                active = active && p < limit;
             }
             if (redo) e_end = p;
             WSYNC();
@@ -763,38 +761,33 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         active = lane < V && n > 0;
         while (__any(active)) {
             STAT_ADD(12, 1);
-            if (active) {
-                uint32_t lo, hi;
-                win_bits(L, w, p, lo, hi);
-                uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-                if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
-                const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
-                uint32_t n1 = cl + eb;
-                uint32_t token = tok_lit(e >> 16);
-                uint32_t st = LS_NONE;
-                if (kind == K_LEN) {
-                    uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-                    uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-                    if ((e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
-                    const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-                    token = tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2));
-                    if (p + n1 + cl2 + eb2 > end_bit) st = LS_NEED_INPUT;
-                    else if (((e2 >> 8) & 3u) == K_BAD) st = LS_BAD;
-                    n1 += cl2 + eb2;
-                } else if (p + n1 > end_bit) st = LS_NEED_INPUT;
-                else if (kind == K_EOB) st = LS_EOB;
-                else if (kind == K_BAD) st = LS_BAD;
-                if (st != LS_NONE) {
-                    lstat = st;
-                    stop_pos = p + cl;  // behind the end-of-block code
-                    active = false;
-                } else {
-                    L.tok[base + k] = token;
-                    k++;
-                    p += n1;
-                    active = k < n;
-                }
-            }
+            // straight-line body (see token_bits); only the token store and the state updates are predicated
+            uint32_t lo, hi;
+            win_bits(L, w, p, lo, hi);
+            uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
+            if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
+            const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+            const uint32_t n1 = cl + eb;
+            const bool islen = kind == K_LEN;
+            const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+            uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
+            if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
+            const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
+            const uint32_t tb = n1 + (islen ? cl2 + eb2 : 0u);
+            const uint32_t token = islen ? tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2)) : tok_lit(e >> 16);
+            // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
+            uint32_t st = LS_NONE;
+            st = (kind == K_BAD || (islen && ((e2 >> 8) & 3u) == K_BAD)) ? (uint32_t)LS_BAD : st;
+            st = kind == K_EOB ? (uint32_t)LS_EOB : st;
+            st = p + tb > end_bit ? (uint32_t)LS_NEED_INPUT : st;
+            const bool go = active && st == LS_NONE;
+            if (go) L.tok[base + k] = token;
+            const bool stop = active && st != LS_NONE;
+            lstat = stop ? st : lstat;
+            stop_pos = stop ? p + cl : stop_pos;  // behind the end-of-block code
+            k += go ? 1u : 0u;
+            p += go ? tb : 0u;
+            active = go && k < n;
         }
         WSYNC();
         const uint64_t stopm = __ballot(lstat != LS_NONE);
