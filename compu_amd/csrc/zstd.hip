@@ -45,6 +45,9 @@ struct alignas(16) ZLds {
     int16_t norm[64];
     uint16_t next[64];
     FseTab wt;  // FSE table of the Huffman weights (accuracy <= 6; only e[0..63] used)
+    uint32_t seqwin[256];  // staged window of the sequence bitstream (read backward)
+    uint32_t xheads[64];   // copy phase: owner of every byte of a 256-byte step
+    uint32_t xpar[192];    // copy phase: per-item parameters
 };
 
 // the unit's input seen as dwords (aligned down), addressed by absolute bit index
@@ -90,6 +93,51 @@ __device__ __forceinline__ bool bb_init(const Bits &b, BackBits &s, uint32_t byt
     s.lo = byte0 * 8u;
     s.avail = (int32_t)((nbytes - 1) * 8u + (31u - (uint32_t)__clz((int)last)));
     return true;
+}
+
+// The sequence bitstream is read through a 1 KiB LDS window that slides backward.
+struct SeqBits {
+    uint32_t lo;      // absolute bit index of the stream start
+    int32_t avail;    // unread bits
+    int32_t win0;     // absolute dword index held in seqwin[0] (may be negative near the start of the input)
+};
+
+__device__ __forceinline__ void sq_fill(ZLds &L, const Bits &b, SeqBits &s)
+{
+    WSYNC();
+    const int32_t top = (int32_t)((s.lo + (uint32_t)(s.avail > 0 ? s.avail : 0)) >> 5);  // dword holding the next bit to read
+    s.win0 = top + 2 - 256;
+    for (int32_t k = (int32_t)lane_id(); k < 256; k += 64) {
+        int32_t i = s.win0 + k;
+        L.seqwin[k] = (i >= 0 && (uint32_t)i < b.total_dw) ? b.g32[i] : 0u;
+    }
+    WSYNC();
+}
+
+// make sure the next `need` bits (<= 160) below the cursor are staged
+__device__ __forceinline__ void sq_ensure(ZLds &L, const Bits &b, SeqBits &s, int32_t need)
+{
+    int32_t lowbit = (int32_t)s.lo + s.avail - need;
+    if (lowbit < (int32_t)s.lo) lowbit = (int32_t)s.lo;
+    if ((lowbit >> 5) < s.win0) sq_fill(L, b, s);
+}
+
+__device__ __forceinline__ uint32_t sq_rd32(const ZLds &L, const SeqBits &s, uint32_t bit)
+{
+    const int32_t i = (int32_t)(bit >> 5) - s.win0;
+    const uint32_t d0 = L.seqwin[i], d1 = L.seqwin[i + 1];
+    return __builtin_amdgcn_alignbit(d1, d0, bit & 31u);
+}
+
+__device__ __forceinline__ uint32_t sq_read(const ZLds &L, SeqBits &s, uint32_t n)
+{
+    uint32_t v = 0;
+    if (n != 0 && s.avail > 0) {
+        if ((uint32_t)s.avail >= n) v = sq_rd32(L, s, s.lo + (uint32_t)s.avail - n) & ((1u << n) - 1u);
+        else v = (sq_rd32(L, s, s.lo) & ((1u << s.avail) - 1u)) << (n - (uint32_t)s.avail);
+    }
+    s.avail -= (int32_t)n;
+    return v;
 }
 
 __device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { return rd32_at(b, byte * 8u) & 0xffu; }
@@ -674,58 +722,197 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                     } else if (!t.valid) ZFAIL(ZSTD_E_CORRUPTION);
                 }
                 WSYNC();
-                BackBits s;
-                if (!bb_init(b, s, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
-                uint32_t sl = bb_read(b, s, L.ll.al), so = bb_read(b, s, L.of.al), sm = bb_read(b, s, L.ml.al);
+                BackBits s0;
+                if (!bb_init(b, s0, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
+                SeqBits s;
+                s.lo = s0.lo;
+                s.avail = s0.avail;
+                sq_fill(L, b, s);
+                uint32_t sl = sq_read(L, s, L.ll.al), so = sq_read(L, s, L.of.al), sm = sq_read(L, s, L.ml.al);
                 if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
-                for (uint32_t i = 0; i < nseq; i++) {
-                    const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
-                    const uint32_t oc = eo & 0xffu, mc = em & 0xffu, lc = el & 0xffu;
-                    if (oc > 31) ZFAIL(ZSTD_E_CORRUPTION);
-                    // offset bits can exceed 24: read in two parts
-                    uint32_t obits = oc > 16 ? (bb_read(b, s, oc - 16) << 16) | bb_read(b, s, 16) : bb_read(b, s, oc);
-                    const uint64_t ov = (1ull << oc) + obits;
-                    const uint32_t mlen = ML_BASE[mc] + bb_read(b, s, ML_BITS[mc]);
-                    const uint32_t llen = LL_BASE[lc] + bb_read(b, s, LL_BITS[lc]);
-                    uint64_t offset;
-                    if (ov > 3) {
-                        offset = ov - 3;
-                        rep2 = rep1;
-                        rep1 = rep0;
-                        rep0 = (uint32_t)offset;
-                    } else {
-                        const uint32_t idx = (uint32_t)ov - (llen != 0 ? 1u : 0u);  // 3 means rep0 - 1
-                        if (idx == 0) offset = rep0;
-                        else {
-                            uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                            t += !t;
-                            if (idx != 1) rep2 = rep1;
+                const uint8_t *litsrc = lit_mode == 0 ? (const uint8_t *)b.g32 + lit_in : gout + lit_out;
+                // sequences are decoded 64 at a time (the FSE state chain is serial; lane j keeps sequence j)
+                // and then executed together: prefix sums place every literal run and match, literal bytes
+                // and match bytes are copied 256 per step with an owner map (see inflate.hip)
+                for (uint32_t i0 = 0; i0 < nseq; i0 += 64) {
+                    const uint32_t cn = nseq - i0 < 64 ? nseq - i0 : 64;
+                    uint32_t ll = 0, ml = 0, off = 0;
+                    uint32_t dec_bad = 64;  // first sequence of the chunk whose decode is corrupt (verdicts keep stream order)
+                    for (uint32_t j = 0; j < cn; j++) {
+                        sq_ensure(L, b, s, 160);
+                        const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
+                        const uint32_t oc = eo & 0xffu, mc = em & 0xffu, lc = el & 0xffu;
+                        if (oc > 31) {
+                            dec_bad = j;
+                            break;
+                        }
+                        const uint32_t obits = oc > 16 ? (sq_read(L, s, oc - 16) << 16) | sq_read(L, s, 16) : sq_read(L, s, oc);
+                        const uint64_t ov = (1ull << oc) + obits;
+                        const uint32_t mlen = ML_BASE[mc] + sq_read(L, s, ML_BITS[mc]);
+                        const uint32_t llen = LL_BASE[lc] + sq_read(L, s, LL_BITS[lc]);
+                        uint64_t offset;
+                        if (ov > 3) {
+                            offset = ov - 3;
+                            rep2 = rep1;
                             rep1 = rep0;
-                            rep0 = t;
-                            offset = t;
+                            rep0 = (uint32_t)offset;
+                        } else {
+                            const uint32_t idx = (uint32_t)ov - (llen != 0 ? 1u : 0u);  // 3 means rep0 - 1
+                            if (idx == 0) offset = rep0;
+                            else {
+                                uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                                t += !t;
+                                if (idx != 1) rep2 = rep1;
+                                rep1 = rep0;
+                                rep0 = t;
+                                offset = t;
+                            }
+                        }
+                        if (i0 + j + 1 < nseq) {
+                            sl = (el >> 16) + sq_read(L, s, (el >> 8) & 0xffu);
+                            sm = (em >> 16) + sq_read(L, s, (em >> 8) & 0xffu);
+                            so = (eo >> 16) + sq_read(L, s, (eo >> 8) & 0xffu);
+                        }
+                        if (s.avail < 0) {
+                            dec_bad = j;
+                            break;
+                        }
+                        if (lane == j) {
+                            ll = llen;
+                            ml = mlen;
+                            off = (uint32_t)offset;
                         }
                     }
-                    if (i + 1 < nseq) {
-                        sl = (el >> 16) + bb_read(b, s, (el >> 8) & 0xffu);
-                        sm = (em >> 16) + bb_read(b, s, (em >> 8) & 0xffu);
-                        so = (eo >> 16) + bb_read(b, s, (eo >> 8) & 0xffu);
+                    // ---- place the chunk ---------------------------------------------------------------
+                    const uint32_t lit_incl = wave_incl_scan(ll), lit_before = lit_incl - ll;
+                    const uint32_t tot = ll + ml, out_incl = wave_incl_scan(tot);
+                    const uint32_t ostart = opos + out_incl - tot, mstart = ostart + ll;
+                    // first failing sequence decides (destination room, literal supply, capacity, offset)
+                    uint32_t fail = 0;
+                    if (lane == dec_bad) fail = 5;
+                    else if (lane < cn && lane < dec_bad) {
+                        if ((uint64_t)ostart + tot > out_limit || (uint64_t)(ostart - block_out0) + tot > BLOCK_MAX) fail = 1;
+                        else if (lit_incl > regen - lpos) fail = 2;
+                        else if ((uint64_t)ostart + tot > cap) fail = 3;
+                        else if (off > mstart) fail = 4;
                     }
-                    if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
-                    // execute: destination room, literal supply, offset (libzstd's order of verdicts)
-                    if ((uint64_t)opos + llen + mlen > out_limit) ZFAIL(70);
-                    if ((uint64_t)(opos - block_out0) + llen + mlen > BLOCK_MAX) ZFAIL(70);
-                    if (llen > regen - lpos) ZFAIL(ZSTD_E_CORRUPTION);
-                    if ((uint64_t)opos + llen + mlen > cap) {
-                        opos = block_out0;  // whole blocks only: see include/compu_hip.h
-                        status = CHIP_NEED_OUTPUT;
-                        goto done;
+                    const uint64_t failm = __ballot(fail != 0);
+                    if (failm) {
+                        const uint32_t f = rdlane(fail, (uint32_t)__ffsll((long long)failm) - 1);
+                        if (f == 1) ZFAIL(70);
+                        if (f == 3) {
+                            opos = block_out0;  // whole blocks only: see include/compu_hip.h
+                            status = CHIP_NEED_OUTPUT;
+                            goto done;
+                        }
+                        ZFAIL(ZSTD_E_CORRUPTION);
                     }
-                    copy_literals(llen);
-                    opos += llen;
-                    lpos += llen;
-                    if (offset > opos) ZFAIL(ZSTD_E_CORRUPTION);
-                    wave_match_copy(gout + opos, (uint32_t)offset, mlen);
-                    opos += mlen;
+                    const uint32_t LB = rdlane(lit_incl, 63), OB = rdlane(out_incl, 63);
+                    // ---- phase A: all literal bytes of the chunk (their sources never depend on this chunk) ----
+                    if (LB) {
+                        WSYNC();
+                        L.xpar[2 * lane] = ostart;
+                        L.xpar[2 * lane + 1] = lit_before;
+                        uint32_t carry = 0;
+                        for (uint32_t wb = 0; wb < LB; wb += 256) {
+                            L.xheads[lane] = 0;
+                            WSYNC();
+                            if (ll && lit_before >= wb && lit_before < wb + 256) ((uint8_t *)L.xheads)[lit_before - wb] = (uint8_t)(lane + 1);
+                            WSYNC();
+                            const uint32_t h = L.xheads[lane];
+                            uint32_t r0 = h & 0xffu, r1 = (h >> 8) & 0xffu, r2 = (h >> 16) & 0xffu, r3 = h >> 24;
+                            r1 = r1 > r0 ? r1 : r0;
+                            r2 = r2 > r1 ? r2 : r1;
+                            r3 = r3 > r2 ? r3 : r2;
+                            uint32_t cin = wave_shr1(wave_incl_max_scan(r3));
+                            cin = cin > carry ? cin : carry;
+                            r0 = r0 > cin ? r0 : cin;
+                            r1 = r1 > cin ? r1 : cin;
+                            r2 = r2 > cin ? r2 : cin;
+                            r3 = r3 > cin ? r3 : cin;
+                            carry = rdlane(r3, 63);
+                            const uint32_t rr[4] = {r0, r1, r2, r3};
+                            uint32_t dsts[4];
+                            uint8_t bytes[4];
+                            bool has[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t q = wb + 4u * lane + j;
+                                has[j] = q < LB && rr[j] != 0;
+                                const uint32_t o = has[j] ? rr[j] - 1u : 0u;
+                                dsts[j] = L.xpar[2 * o] + (q - L.xpar[2 * o + 1]);
+                                bytes[j] = lit_mode == 1 ? (uint8_t)lit_rle : litsrc[has[j] ? lpos + q : 0u];
+                            }
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (has[j]) gout[dsts[j]] = bytes[j];
+                            WSYNC();
+                        }
+                    }
+                    // ---- phase B: matches, several per step as long as none reads what the step writes ----------
+                    {
+                        const uint32_t mbi = wave_incl_scan(ml), mbx = mbi - ml;
+                        const uint32_t srcend = mstart - off + (ml < off ? ml : off);
+                        uint64_t mm = __ballot(ml != 0);
+                        while (mm) {
+                            const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
+                            const uint32_t d0 = rdlane(mstart, k0), b0 = rdlane(mbx, k0), l0 = rdlane(ml, k0);
+                            if (l0 > 256) {
+                                wave_match_copy(gout + d0, rdlane(off, k0), l0);
+                                mm &= mm - 1;
+                                continue;
+                            }
+                            const uint64_t okm = __ballot(ml && (mbi - b0 <= 256u) && (lane == k0 || srcend <= d0));
+                            const uint64_t rem = mm & ~okm;
+                            const uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
+                            const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
+                            const uint32_t nbytes = rdlane(mbi, lastl) - b0;
+                            L.xheads[lane] = 0;
+                            WSYNC();
+                            if ((inc >> lane) & 1ull) {
+                                const uint32_t rank = (uint32_t)__popcll(inc & lanemask_lt());
+                                const uint32_t rel = mbx - b0;
+                                ((uint8_t *)L.xheads)[rel] = (uint8_t)(rank + 1);
+                                L.xpar[3 * rank] = mstart;
+                                L.xpar[3 * rank + 1] = off;
+                                L.xpar[3 * rank + 2] = (ml - 1u) | (rel << 8);
+                            }
+                            WSYNC();
+                            const uint32_t h = L.xheads[lane];
+                            uint32_t r0 = h & 0xffu, r1 = (h >> 8) & 0xffu, r2 = (h >> 16) & 0xffu, r3 = h >> 24;
+                            r1 = r1 > r0 ? r1 : r0;
+                            r2 = r2 > r1 ? r2 : r1;
+                            r3 = r3 > r2 ? r3 : r2;
+                            const uint32_t cin = wave_shr1(wave_incl_max_scan(r3));
+                            r0 = r0 > cin ? r0 : cin;
+                            r1 = r1 > cin ? r1 : cin;
+                            r2 = r2 > cin ? r2 : cin;
+                            r3 = r3 > cin ? r3 : cin;
+                            const uint32_t rr[4] = {r0, r1, r2, r3};
+                            uint32_t srcs[4], dsts[4];
+                            bool has[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) {
+                                const uint32_t q = 4u * lane + j;
+                                has[j] = q < nbytes && rr[j] != 0;
+                                const uint32_t r = has[j] ? rr[j] - 1u : 0u;
+                                const uint32_t st = L.xpar[3 * r], ds = L.xpar[3 * r + 1], pv = L.xpar[3 * r + 2];
+                                const uint32_t ln = (pv & 0xffu) + 1u, o = q - (pv >> 8);
+                                dsts[j] = st + o;
+                                srcs[j] = st - ds + (ds >= ln ? o : o % ds);
+                            }
+                            uint8_t bytes[4];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) bytes[j] = gout[has[j] ? srcs[j] : 0u];
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if (has[j]) gout[dsts[j]] = bytes[j];
+                            WSYNC();
+                            mm &= ~inc;
+                        }
+                    }
+                    opos += OB;
+                    lpos += LB;
                 }
                 if (s.avail != 0) ZFAIL(ZSTD_E_CORRUPTION);  // the bitstream must be consumed exactly
             }
