@@ -45,6 +45,7 @@ struct alignas(16) ZLds {
     int16_t norm[64];
     uint16_t next[64];
     FseTab wt;  // FSE table of the Huffman weights (accuracy <= 6; only e[0..63] used)
+    uint32_t lltab[36], mltab[53];  // sequence code -> baseline | extra bits << 24 (kept on chip: read once per sequence)
     uint32_t seqwin[256];  // staged window of the sequence bitstream (read backward)
     uint32_t xheads[64];   // copy phase: owner of every byte of a 256-byte step
     uint32_t xpar[192];    // copy phase: per-item parameters
@@ -95,18 +96,21 @@ __device__ __forceinline__ bool bb_init(const Bits &b, BackBits &s, uint32_t byt
     return true;
 }
 
-// The sequence bitstream is read through a 1 KiB LDS window that slides backward.
+// The sequence bitstream is read backward through a 1 KiB LDS window and a 64-bit register buffer
+// (next bit at bit 63): one LDS read per 32 consumed bits instead of two per field.
 struct SeqBits {
-    uint32_t lo;      // absolute bit index of the stream start
-    int32_t avail;    // unread bits
-    int32_t win0;     // absolute dword index held in seqwin[0] (may be negative near the start of the input)
+    uint32_t lo;    // absolute bit index of the stream start
+    int32_t avail;  // unread bits of the stream (negative once over-read)
+    int32_t win0;   // absolute dword index held in seqwin[0]
+    uint64_t buf;   // unread bits, left aligned
+    int32_t cnt;    // valid bits in buf
+    int32_t ptr;    // absolute bit index of the lowest bit already in buf
 };
 
 __device__ __forceinline__ void sq_fill(ZLds &L, const Bits &b, SeqBits &s)
 {
     WSYNC();
-    const int32_t top = (int32_t)((s.lo + (uint32_t)(s.avail > 0 ? s.avail : 0)) >> 5);  // dword holding the next bit to read
-    s.win0 = top + 2 - 256;
+    s.win0 = (s.ptr >> 5) + 2 - 256;
     for (int32_t k = (int32_t)lane_id(); k < 256; k += 64) {
         int32_t i = s.win0 + k;
         L.seqwin[k] = (i >= 0 && (uint32_t)i < b.total_dw) ? b.g32[i] : 0u;
@@ -114,28 +118,52 @@ __device__ __forceinline__ void sq_fill(ZLds &L, const Bits &b, SeqBits &s)
     WSYNC();
 }
 
-// make sure the next `need` bits (<= 160) below the cursor are staged
+// make sure the dwords the next `need` bits (<= 160) come from are staged
 __device__ __forceinline__ void sq_ensure(ZLds &L, const Bits &b, SeqBits &s, int32_t need)
 {
-    int32_t lowbit = (int32_t)s.lo + s.avail - need;
+    int32_t lowbit = s.ptr - need;
     if (lowbit < (int32_t)s.lo) lowbit = (int32_t)s.lo;
     if ((lowbit >> 5) < s.win0) sq_fill(L, b, s);
 }
 
-__device__ __forceinline__ uint32_t sq_rd32(const ZLds &L, const SeqBits &s, uint32_t bit)
+// pull the next lower dword of the stream into the register buffer (bits below the stream start are zero)
+__device__ __forceinline__ void sq_refill(const ZLds &L, SeqBits &s)
 {
-    const int32_t i = (int32_t)(bit >> 5) - s.win0;
-    const uint32_t d0 = L.seqwin[i], d1 = L.seqwin[i + 1];
-    return __builtin_amdgcn_alignbit(d1, d0, bit & 31u);
+    s.ptr -= 32;
+    uint32_t dw = 0;
+    if (s.ptr + 32 > (int32_t)s.lo) {
+        dw = L.seqwin[(s.ptr >> 5) - s.win0];
+        if (s.ptr < (int32_t)s.lo) dw &= ~((1u << ((int32_t)s.lo - s.ptr)) - 1u);
+    }
+    s.buf |= (uint64_t)dw << (32 - s.cnt);
+    s.cnt += 32;
 }
 
-__device__ __forceinline__ uint32_t sq_read(const ZLds &L, SeqBits &s, uint32_t n)
+__device__ __forceinline__ void sq_init(ZLds &L, const Bits &b, SeqBits &s, uint32_t lo, int32_t avail)
 {
-    uint32_t v = 0;
-    if (n != 0 && s.avail > 0) {
-        if ((uint32_t)s.avail >= n) v = sq_rd32(L, s, s.lo + (uint32_t)s.avail - n) & ((1u << n) - 1u);
-        else v = (sq_rd32(L, s, s.lo) & ((1u << s.avail) - 1u)) << (n - (uint32_t)s.avail);
+    s.lo = lo;
+    s.avail = avail;
+    const uint32_t top = lo + (uint32_t)avail;
+    s.ptr = (int32_t)top;
+    s.buf = 0;
+    s.cnt = 0;
+    sq_fill(L, b, s);
+    if (top & 31u) {  // partial top dword
+        const uint32_t k = top & 31u;
+        uint32_t dw = L.seqwin[(int32_t)(top >> 5) - s.win0] & ((1u << k) - 1u);
+        s.ptr = (int32_t)(top & ~31u);
+        if (s.ptr < (int32_t)lo) dw &= ~((1u << ((int32_t)lo - s.ptr)) - 1u);
+        s.buf = (uint64_t)dw << (64 - k);
+        s.cnt = (int32_t)k;
     }
+}
+
+__device__ __forceinline__ uint32_t sq_read(const ZLds &L, SeqBits &s, uint32_t n)  // n <= 32
+{
+    if (s.cnt <= 32) sq_refill(L, s);
+    const uint32_t v = n ? (uint32_t)(s.buf >> (64 - n)) : 0u;
+    s.buf = n ? s.buf << n : s.buf;
+    s.cnt -= (int32_t)n;
     s.avail -= (int32_t)n;
     return v;
 }
@@ -363,10 +391,12 @@ __device__ uint32_t wave_xxh64_low32(const uint8_t *p, uint32_t n)
     constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
                        P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
     auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    const uint32_t pmis = (uint32_t)((uintptr_t)p & 3u);
+    const uint32_t *p32 = (const uint32_t *)(p - pmis);  // aligned view; reads stay inside dwords that hold bytes of p[0..n)
     auto rd64 = [&](uint32_t off) {
-        uint64_t v = 0;
-        for (int k = 7; k >= 0; k--) v = (v << 8) | p[off + (uint32_t)k];
-        return v;
+        const uint32_t i = (pmis + off) >> 2, sh = ((pmis + off) & 3u) * 8u;
+        const uint32_t d0 = p32[i], d1 = p32[i + 1], d2 = sh ? p32[i + 2] : 0u;
+        return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
     };
     auto round1 = [&](uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; };
     const uint32_t lane = lane_id();
@@ -469,6 +499,8 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
         L.huf_valid = 0;
         L.ll.valid = L.of.valid = L.ml.valid = 0;
     }
+    if (lane < 36) L.lltab[lane] = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
+    if (lane < 53) L.mltab[lane] = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
     WSYNC();
 
 #define ZFAIL(code) do { status = -(code); goto done; } while (0)
@@ -618,7 +650,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                 }
                 lit_mode = 2;
                 lit_out = cap - regen;
-                uint32_t sz[4] = {lleft, 0, 0, 0}, cnt[4] = {regen, 0, 0, 0};
+                uint32_t sz[4] = {lleft, 0, 0, 0}, cnt_[4] = {regen, 0, 0, 0};
                 uint32_t st0 = lp;
                 if (streams == 4) {
                     if (lleft < 10) ZFAIL(ZSTD_E_CORRUPTION);
@@ -630,8 +662,8 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                     sz[3] = lleft - 6 - sz[0] - sz[1] - sz[2];
                     const uint32_t seg = (regen + 3) / 4;
                     if (seg * 3 > regen) ZFAIL(ZSTD_E_CORRUPTION);
-                    cnt[0] = cnt[1] = cnt[2] = seg;
-                    cnt[3] = regen - 3 * seg;
+                    cnt_[0] = cnt_[1] = cnt_[2] = seg;
+                    cnt_[3] = regen - 3 * seg;
                     st0 = lp + 6;
                 }
                 // lanes 0..3 each decode one stream, symbol by symbol
@@ -640,23 +672,52 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                     uint32_t myoff = st0, myout = lit_out;
                     for (uint32_t k = 0; k < lane; k++) {
                         myoff += sz[k];
-                        myout += cnt[k];
+                        myout += cnt_[k];
                     }
                     BackBits s;
                     if (!bb_init(b, s, myoff, sz[lane])) sbad = true;
                     else {
+                        // per-lane register bit buffer (next bit at bit 63) fed by aligned dword loads issued one
+                        // refill ahead, so the table lookup is the only latency on the symbol chain
+                        const int32_t lo = (int32_t)s.lo;
+                        auto load_dw = [&](int32_t bit) -> uint32_t {
+                            const int32_t i = bit >> 5;
+                            if (bit + 32 <= lo || i < 0 || (uint32_t)i >= b.total_dw) return 0u;
+                            uint32_t dw = b.g32[i];
+                            if (bit < lo) dw &= ~((1u << (lo - bit)) - 1u);
+                            return dw;
+                        };
+                        const uint32_t top = s.lo + (uint32_t)s.avail;
+                        int32_t ptr = (int32_t)(top & ~31u), cnt = (int32_t)(top & 31u);
+                        uint64_t buf = cnt ? (uint64_t)(load_dw(ptr) & ((1u << cnt) - 1u)) << (64 - cnt) : 0ull;
+                        uint32_t nextdw = load_dw(ptr - 32);
+                        int32_t avail = s.avail;
                         const uint32_t hbits = L.huf_bits;
-                        const uint32_t ncnt = cnt[lane];
+#ifdef CHIP_EXP_NOHUF
+                        const uint32_t ncnt = 0;
+                        avail = 0;
+#else
+                        const uint32_t ncnt = cnt_[lane];
+#endif
                         for (uint32_t i = 0; i < ncnt; i++) {
-                            uint32_t e = L.huf[bb_peek(b, s, hbits)];
+                            if (cnt <= 32) {
+                                ptr -= 32;
+                                buf |= (uint64_t)nextdw << (32 - cnt);
+                                cnt += 32;
+                                nextdw = load_dw(ptr - 32);
+                            }
+                            const uint32_t e = L.huf[(uint32_t)(buf >> (64 - hbits))];
+                            const uint32_t nb = e >> 8;
                             gout[myout + i] = (uint8_t)e;
-                            s.avail -= (int32_t)(e >> 8);
-                            if (s.avail < 0) {
+                            buf <<= nb;
+                            cnt -= (int32_t)nb;
+                            avail -= (int32_t)nb;
+                            if (avail < 0) {
                                 sbad = true;
                                 break;
                             }
                         }
-                        if (s.avail != 0) sbad = true;  // the stream must be consumed exactly
+                        if (avail != 0) sbad = true;  // the stream must be consumed exactly
                     }
                 }
                 if (__any(sbad)) ZFAIL(ZSTD_E_CORRUPTION);
@@ -725,9 +786,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                 BackBits s0;
                 if (!bb_init(b, s0, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
                 SeqBits s;
-                s.lo = s0.lo;
-                s.avail = s0.avail;
-                sq_fill(L, b, s);
+                sq_init(L, b, s, s0.lo, s0.avail);
                 uint32_t sl = sq_read(L, s, L.ll.al), so = sq_read(L, s, L.of.al), sm = sq_read(L, s, L.ml.al);
                 if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
                 const uint8_t *litsrc = lit_mode == 0 ? (const uint8_t *)b.g32 + lit_in : gout + lit_out;
@@ -748,8 +807,13 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                         }
                         const uint32_t obits = oc > 16 ? (sq_read(L, s, oc - 16) << 16) | sq_read(L, s, 16) : sq_read(L, s, oc);
                         const uint64_t ov = (1ull << oc) + obits;
-                        const uint32_t mlen = ML_BASE[mc] + sq_read(L, s, ML_BITS[mc]);
-                        const uint32_t llen = LL_BASE[lc] + sq_read(L, s, LL_BITS[lc]);
+                        if (mc > 52 || lc > 35) {
+                            dec_bad = j;
+                            break;
+                        }
+                        const uint32_t mt = L.mltab[mc], lt = L.lltab[lc];
+                        const uint32_t mlen = (mt & 0xffffffu) + sq_read(L, s, mt >> 24);
+                        const uint32_t llen = (lt & 0xffffffu) + sq_read(L, s, lt >> 24);
                         uint64_t offset;
                         if (ov > 3) {
                             offset = ov - 3;
@@ -809,6 +873,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                     }
                     const uint32_t LB = rdlane(lit_incl, 63), OB = rdlane(out_incl, 63);
                     // ---- phase A: all literal bytes of the chunk (their sources never depend on this chunk) ----
+#ifndef CHIP_EXP_NOEXEC
                     if (LB) {
                         WSYNC();
                         L.xpar[2 * lane] = ostart;
@@ -911,6 +976,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                             mm &= ~inc;
                         }
                     }
+#endif
                     opos += OB;
                     lpos += LB;
                 }
@@ -936,7 +1002,9 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
     if (has_checksum) {
         if (END - ip < 4) ZNEED_INPUT();
         uint32_t want = rd32_at(b, ip * 8u);
+#ifndef CHIP_EXP_NOXXH
         if (wave_xxh64_low32(gout, opos) != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);
+#endif
         ip += 4;
     }
     status = CHIP_FINISHED;
