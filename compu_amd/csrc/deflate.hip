@@ -21,12 +21,11 @@ namespace {
 
 constexpr int HASH_BITS = 12;
 constexpr uint32_t MIN_MATCH = 4, MAX_MATCH = 258, MAX_DIST = 32768;
-constexpr int OUT_DW = 1024;  // LDS bit buffer, dwords
+constexpr int OUT_DW = 448;  // LDS bit buffer, dwords (a chunk adds at most 62)
 
 struct alignas(16) ELds {
     uint32_t table[1 << HASH_BITS];
     uint32_t obuf[OUT_DW + 64];
-    uint32_t crc_tab[256];
 };
 
 // 4 input bytes at byte offset `off` of the dword-aligned view (little endian)
@@ -216,14 +215,23 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
             }
             WSYNC();  // every lookup saw the table as it stood before this chunk
             if (valid4) atomicMax(&L.table[h], p + 1);
-            // greedy choice, left to right over the chunk
+            // greedy choice, left to right over the chunk: jump from selected match to selected match (a scalar
+            // step per chosen match, not per position); everything in between is a literal
+            const uint32_t lim64 = n - base < 64 ? n - base : 64;
+            const uint64_t limmask = lim64 >= 64 ? ~0ull : ((1ull << lim64) - 1ull);
+            const uint64_t cand = __ballot(mlen >= MIN_MATCH) & limmask;
             uint64_t sel = 0;
             uint32_t pos = skip;
-            const uint32_t lim64 = n - base < 64 ? n - base : 64;
             while (pos < lim64) {
-                uint32_t ml = rdlane(mlen, pos);
-                sel |= 1ull << pos;
-                pos += ml >= MIN_MATCH ? ml : 1u;
+                const uint64_t rest = cand & ~((1ull << pos) - 1ull);
+                if (!rest) {
+                    sel |= limmask & ~((1ull << pos) - 1ull);
+                    pos = lim64;
+                    break;
+                }
+                const uint32_t c = (uint32_t)__ffsll((long long)rest) - 1;
+                sel |= ((c >= 63 ? ~0ull : ((2ull << c) - 1ull))) & ~((1ull << pos) - 1ull);
+                pos = c + rdlane(mlen, c);
             }
             skip = pos > 64 ? pos - 64 : 0;
             const bool mine = (sel >> lane) & 1ull;
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     }
     // ---- checksum / trailer -----------------------------------------------------------------------
     uint32_t check = a.check_seed;
-    if (fmt == CHIP_FMT_GZIP) check = wave_crc32(L.crc_tab, gin, n, a.check_seed);
+    if (fmt == CHIP_FMT_GZIP) check = wave_crc32(L.table, gin, n, a.check_seed);  // the hash table is dead by now
     else if (fmt == CHIP_FMT_ZLIB) check = wave_adler32(gin, n, a.check_seed);
     if (trl && fmt == CHIP_FMT_GZIP) {
         const uint32_t isize = (uint32_t)(a.total_before + n);
