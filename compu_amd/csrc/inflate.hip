@@ -988,10 +988,20 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
             }
             // code lengths of the two alphabets (sequential: each symbol's position depends on the previous)
             uint32_t have = 0, total = nlen + ndist, prev = 0;
+            // the whole section (<= 316 symbols of <= 14 bits) is staged once and read through a 64-bit
+            // register window, so the only latency per symbol is the code-length table lookup
+            win_ensure(L, w, pos, 316 * 14 + 64);
+            uint32_t nxt = (pos >> 5) - w.win0;
+            uint64_t bb = (((uint64_t)L.inbuf[nxt + 1] << 32) | L.inbuf[nxt]) >> (pos & 31u);
+            uint32_t cnt = 64u - (pos & 31u);
+            nxt += 2;
             while (have < total) {
-                win_ensure(L, w, pos);
-                win_bits(L, w, pos, lo, hi);
-                uint32_t e = L.hdr.cl_lut[lo & 127u];
+                if (cnt < 32) {
+                    bb |= (uint64_t)L.inbuf[nxt++] << cnt;
+                    cnt += 32;
+                }
+                const uint32_t lo32 = (uint32_t)bb;
+                uint32_t e = L.hdr.cl_lut[lo32 & 127u];
                 uint32_t cl = e & 15u, sym = e >> 16;
                 if (sym < 16) {
                     if (pos + cl > end_bit) {
@@ -1002,6 +1012,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                     prev = sym;
                     have++;
                     pos += cl;
+                    bb >>= cl;
+                    cnt -= cl;
                     continue;
                 }
                 uint32_t eb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
@@ -1009,7 +1021,7 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                     status = CHIP_NEED_INPUT;
                     break;
                 }
-                uint32_t rep = (sym == 18 ? 11u : 3u) + bfe(lo, cl, eb);
+                uint32_t rep = (sym == 18 ? 11u : 3u) + bfe(lo32, cl, eb);
                 uint32_t val = 0;
                 if (sym == 16) {
                     if (have == 0) {
@@ -1027,6 +1039,8 @@ __global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
                 for (uint32_t j = lane; j < rep; j += 64) L.hdr.lens[have + j] = (uint8_t)val;
                 have += rep;
                 pos += cl + eb;
+                bb >>= cl + eb;
+                cnt -= cl + eb;
             }
             if (status != ST_RUNNING) break;
             WSYNC();
