@@ -146,3 +146,59 @@ def test_truncated_corrupt_and_small_caps_match_oracle(gpu, alice):
         assert st[i] == r_st, (i, st[i], r_st)
         if r_st == 2:
             assert iu[i] == r_used, (i, iu[i], r_used)
+
+
+def test_large_multiblock_streams(gpu, alice):
+    """Streams far larger than a 64 KiB unit: many blocks of every type, window reloads, matches that reach the
+    full 32 KiB window across block boundaries, highly compressible runs (258-byte matches, distance 1)."""
+    import compu_amd
+
+    rnd = random.Random(99)
+    big = bytearray()
+    while len(big) < 6_000_000:
+        k = rnd.randrange(6)
+        if k == 0:
+            big += alice[rnd.randrange(len(alice) // 2) :][: rnd.randrange(1, 200000)]
+        elif k == 1:
+            big += rnd.randbytes(rnd.randrange(1, 70000))
+        elif k == 2:
+            big += b"\0" * rnd.randrange(1, 300000)
+        elif k == 3:
+            big += bytes(rnd.choice(b"abc") for _ in range(rnd.randrange(1, 20000)))
+        elif k == 4:
+            big += big[-rnd.randrange(1, min(len(big), 32768) + 1) :][: rnd.randrange(1, 5000)] if big else b"x"
+        else:
+            big += bytes([rnd.randrange(256)]) * rnd.randrange(1, 1000)
+    big = bytes(big)
+    cases = []
+    for level, wb in ((6, 31), (1, -15), (9, 15), (0, -15)):
+        co = zlib.compressobj(level, zlib.DEFLATED, wb)
+        comp = b""
+        pos = 0
+        while pos < len(big):  # flushes force extra block boundaries, incl. empty stored blocks
+            step = rnd.randrange(1, 400000)
+            comp += co.compress(big[pos : pos + step])
+            if rnd.random() < 0.3:
+                comp += co.flush(rnd.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH]))
+            pos += step
+        comp += co.flush()
+        cases.append((wb, comp))
+    # batch API
+    for wb, comp in cases:
+        outs, ol, iu, st = run_batch(gpu, wb, [comp], [len(big)])
+        assert st[0] == 2 and iu[0] == len(comp) and outs[0] == big, (wb, st[0], ol[0])
+    # streaming decoder in 64 KiB input chunks and 100 KB output buffers
+    wb, comp = cases[0]
+    dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+    out = bytearray()
+    buf = bytearray(100_000)
+    pos = 0
+    while True:
+        chunk = comp[pos : pos + 65536]
+        r = dec.decode(chunk, buf)
+        assert r.is_ok()
+        out += buf[: len(buf) - r.output_remain]
+        pos += len(chunk) - r.input_remain
+        if r.status == compu_amd.DecodeStatus.Finished:
+            break
+    assert bytes(out) == big and pos == len(comp)

@@ -161,3 +161,28 @@ def test_mixed_gzip_zstd_batch_routed_by_detection(gpu, alice):
     assert q[:2] == b"\x68\x81" and compu_amd.Detection.detect(q) == compu_amd.Detection.Unknown
     outs, ol, iu, st = run_batch(gpu, 0, [q], [16], check_tail=False)
     assert st[0] == 4
+
+
+def test_large_multiblock_frames(gpu, alice):
+    """Frames of several MB: many 128 KiB blocks, repeat-mode tables, treeless literals, matches far beyond
+    one block (window up to 8 MiB at level 19), raw and RLE blocks."""
+    z = zstd_ref.load()
+    rnd = random.Random(5)
+    big = bytearray()
+    while len(big) < 5_000_000:
+        k = rnd.randrange(5)
+        if k == 0:
+            big += alice[rnd.randrange(len(alice) // 2) :][: rnd.randrange(1, 200000)]
+        elif k == 1:
+            big += rnd.randbytes(rnd.randrange(1, 200000))
+        elif k == 2:
+            big += b"\0" * rnd.randrange(1, 400000)
+        elif k == 3:
+            big += bytes(rnd.choice(b"abc") for _ in range(rnd.randrange(1, 20000)))
+        else:
+            big += big[-rnd.randrange(1, len(big) + 1) :][: rnd.randrange(1, 50000)] if big else b"x"
+    big = bytes(big)
+    for level in (1, 3, 19):
+        comp = zstd_ref.compress(z, big, level, True, True)
+        outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, [comp], [len(big)], check_tail=False)
+        assert st[0] == 2 and iu[0] == len(comp) and outs[0] == big, (level, st[0], ol[0])
