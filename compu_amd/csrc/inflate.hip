@@ -63,7 +63,7 @@ constexpr int CL_ROOT = 7;
 #define CHIP_S_BITS 160
 #define CHIP_O_BITS 160
 #define CHIP_TOK_CAP 864
-#define CHIP_FIX_ROUNDS 5
+#define CHIP_FIX_ROUNDS 12  // upper bound; the loop ends as soon as every live lane has merged
 #endif
 constexpr int S_BITS = CHIP_S_BITS;
 constexpr int O_BITS = CHIP_O_BITS;
@@ -843,7 +843,10 @@ __device__ void finish_tables(WaveLds &L)
     WSYNC();
 }
 
-__global__ __launch_bounds__(64) void inflate_kernel(BatchArgs a)
+#ifndef CHIP_WAVES_PER_SIMD
+#define CHIP_WAVES_PER_SIMD 1
+#endif
+__global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchArgs a)
 {
     __shared__ WaveLds L;
     const uint32_t u = blockIdx.x;
