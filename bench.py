@@ -101,7 +101,7 @@ def run_encode(torch, compu_amd, payload_dev, n_units, steps, warmup, dist):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
@@ -152,7 +152,7 @@ def run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps,
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
@@ -219,12 +219,19 @@ def main():
     if world != args.gpus:
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    # rehearsal knobs (not used by the driver): several ranks on one GPU need gloo, NCCL/RCCL refuses duplicate devices
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    if "BENCH_DEVICE_OVERRIDE" in os.environ:
+        local_rank = int(os.environ["BENCH_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
 
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist_mod.init_process_group(backend=backend)
         dist = dist_mod
     compu_amd.lib().chip_set_device(local_rank)
 
