@@ -802,7 +802,12 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         STAT_ACC(4);
         STAT_ADD(10, T);
         int32_t st2 = ST_RUNNING;
+#ifdef CHIP_EXP_NOFLUSH
+        bool flushed = true;
+        opos += T;
+#else
         bool flushed = flush_tokens(L, T, gout, opos, cap, st2 STAT_ARG);
+#endif
         STAT_ACC(20);
         if (!flushed) {
             status = st2;
