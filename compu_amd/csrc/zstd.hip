@@ -31,20 +31,30 @@ __device__ const int8_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 
 __device__ const int8_t ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 
 // FSE decode entry: [7:0] symbol, [15:8] number of bits to read, [31:16] baseline of the next state
-struct FseTab {
-    uint32_t e[512];
+template <int N>
+struct FseTabN {
+    uint32_t e[N];
     uint32_t al;
     uint32_t valid;
 };
+using FseTab = FseTabN<512>;   // literal-length / match-length tables (accuracy <= 9)
+using FseTabOf = FseTabN<256>; // offset table (accuracy <= 8)
+using FseTabWt = FseTabN<64>;  // Huffman-weight table (accuracy <= 6)
+struct FseView {  // the builders work on any of the three sizes
+    uint32_t *e, *al, *valid;
+};
+template <int N>
+__device__ __forceinline__ FseView view(FseTabN<N> &t) { return FseView{t.e, &t.al, &t.valid}; }
 
 struct alignas(16) ZLds {
     uint16_t huf[2048];  // [7:0] symbol, [11:8] code length
-    FseTab ll, of, ml;
+    FseTab ll, ml;
+    FseTabOf of;
     uint32_t huf_bits, huf_valid;
     uint8_t weights[256];
     int16_t norm[64];
     uint16_t next[64];
-    FseTab wt;  // FSE table of the Huffman weights (accuracy <= 6; only e[0..63] used)
+    FseTabWt wt;  // FSE table of the Huffman weights
     uint32_t lltab[36], mltab[53];  // sequence code -> baseline | extra bits << 24 (kept on chip: read once per sequence)
     uint32_t seqwin[256];  // staged window of the sequence bitstream (read backward)
     uint32_t xheads[64];   // copy phase: owner of every byte of a 256-byte step
@@ -126,17 +136,18 @@ __device__ __forceinline__ void sq_ensure(ZLds &L, const Bits &b, SeqBits &s, in
     if ((lowbit >> 5) < s.win0) sq_fill(L, b, s);
 }
 
-// pull the next lower dword of the stream into the register buffer (bits below the stream start are zero)
+// Pull the next lower dword of the stream into the register buffer when 32 bits or fewer are left --
+// branch-free.  Bits below the stream start are whatever precedes it in the input: a read that reaches
+// them drives `avail` negative, which the caller treats as corruption whatever the bits were.
 __device__ __forceinline__ void sq_refill(const ZLds &L, SeqBits &s)
 {
-    s.ptr -= 32;
-    uint32_t dw = 0;
-    if (s.ptr + 32 > (int32_t)s.lo) {
-        dw = L.seqwin[(s.ptr >> 5) - s.win0];
-        if (s.ptr < (int32_t)s.lo) dw &= ~((1u << ((int32_t)s.lo - s.ptr)) - 1u);
-    }
-    s.buf |= (uint64_t)dw << (32 - s.cnt);
-    s.cnt += 32;
+    const bool need = s.cnt <= 32;
+    int32_t i = ((s.ptr - 32) >> 5) - s.win0;
+    i = i < 0 ? 0 : i;
+    const uint32_t dw = L.seqwin[i];
+    s.buf |= need ? (uint64_t)dw << (32 - s.cnt) : 0ull;
+    s.cnt += need ? 32 : 0;
+    s.ptr -= need ? 32 : 0;
 }
 
 __device__ __forceinline__ void sq_init(ZLds &L, const Bits &b, SeqBits &s, uint32_t lo, int32_t avail)
@@ -160,7 +171,7 @@ __device__ __forceinline__ void sq_init(ZLds &L, const Bits &b, SeqBits &s, uint
 
 __device__ __forceinline__ uint32_t sq_read(const ZLds &L, SeqBits &s, uint32_t n)  // n <= 32
 {
-    if (s.cnt <= 32) sq_refill(L, s);
+    sq_refill(L, s);
     const uint32_t v = n ? (uint32_t)(s.buf >> (64 - n)) : 0u;
     s.buf = n ? s.buf << n : s.buf;
     s.cnt -= (int32_t)n;
@@ -228,7 +239,7 @@ __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, 
 }
 
 // FSE decoding table from normalized counts in L.norm (sec. 4.1.1).  Uniform; lane 0 writes.
-__device__ int fse_build(ZLds &L, FseTab &t, int nsym, int al)
+__device__ int fse_build(ZLds &L, FseView t, int nsym, int al)
 {
     WSYNC();
     const bool w = lane_id() == 0;
@@ -262,20 +273,20 @@ __device__ int fse_build(ZLds &L, FseTab &t, int nsym, int al)
             uint32_t nb = (uint32_t)al - (31u - (uint32_t)__clz((int)ns));
             t.e[u] = s | (nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xffffu) << 16);
         }
-        t.al = (uint32_t)al;
-        t.valid = 1;
+        *t.al = (uint32_t)al;
+        *t.valid = 1;
     }
     WSYNC();
     return 0;
 }
 
-__device__ void fse_rle(FseTab &t, uint32_t sym)
+__device__ void fse_rle(FseView t, uint32_t sym)
 {
     WSYNC();
     if (lane_id() == 0) {
         t.e[0] = sym;
-        t.al = 0;
-        t.valid = 1;
+        *t.al = 0;
+        *t.valid = 1;
     }
     WSYNC();
 }
@@ -351,7 +362,7 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
         int al, nsym;
         int c = fse_read_ncount(L, b, p0 + 1, hb, 6, 12, al, nsym);
         if (c < 0) return -1;
-        if (fse_build(L, L.wt, nsym, al)) return -1;
+        if (fse_build(L, view(L.wt), nsym, al)) return -1;
         BackBits s;
         if (!bb_init(b, s, p0 + 1 + (uint32_t)c, hb - (uint32_t)c)) return -1;
         uint32_t s1 = bb_read(b, s, (uint32_t)al), s2 = bb_read(b, s, (uint32_t)al);
@@ -470,7 +481,10 @@ __device__ void wave_match_copy(uint8_t *dst, uint32_t offset, uint32_t n)
     }
 }
 
-__global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
+#ifndef CHIP_ZSTD_WAVES
+#define CHIP_ZSTD_WAVES 3  // waves per SIMD the register budget is set for; LDS (12.4 KB) allows 12 per CU
+#endif
+__global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, int wlog_max)
 {
     __shared__ ZLds L;
     const uint32_t u = blockIdx.x;
@@ -758,7 +772,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                 left -= 1;
                 if (modes & 3u) ZFAIL(ZSTD_E_CORRUPTION);
                 for (int k = 0; k < 3; k++) {
-                    FseTab &t = k == 0 ? L.ll : k == 1 ? L.of : L.ml;
+                    const FseView t = k == 0 ? view(L.ll) : k == 1 ? view(L.of) : view(L.ml);
                     const int maxal = k == 1 ? 8 : 9, maxsym = k == 0 ? 35 : k == 1 ? 31 : 52;
                     const uint32_t mode = (modes >> (6 - 2 * k)) & 3u;
                     if (mode == 0) {
@@ -780,7 +794,7 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                         if (fse_build(L, t, nsym, al)) ZFAIL(ZSTD_E_CORRUPTION);
                         p += (uint32_t)c;
                         left -= (uint32_t)c;
-                    } else if (!t.valid) ZFAIL(ZSTD_E_CORRUPTION);
+                    } else if (!*t.valid) ZFAIL(ZSTD_E_CORRUPTION);
                 }
                 WSYNC();
                 BackBits s0;
@@ -805,15 +819,19 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                             dec_bad = j;
                             break;
                         }
-                        const uint32_t obits = oc > 16 ? (sq_read(L, s, oc - 16) << 16) | sq_read(L, s, 16) : sq_read(L, s, oc);
+                        // three reads per sequence: the offset's extra bits, then the match- and literal-length
+                        // extras together (<= 32 bits), and further down the three state updates together
+                        const uint32_t obits = sq_read(L, s, oc);
                         const uint64_t ov = (1ull << oc) + obits;
                         if (mc > 52 || lc > 35) {
                             dec_bad = j;
                             break;
                         }
                         const uint32_t mt = L.mltab[mc], lt = L.lltab[lc];
-                        const uint32_t mlen = (mt & 0xffffffu) + sq_read(L, s, mt >> 24);
-                        const uint32_t llen = (lt & 0xffffffu) + sq_read(L, s, lt >> 24);
+                        const uint32_t mb = mt >> 24, lb = lt >> 24;
+                        const uint32_t mlx = sq_read(L, s, mb + lb);
+                        const uint32_t mlen = (mt & 0xffffffu) + (lb >= 32 ? 0u : (mlx >> lb));
+                        const uint32_t llen = (lt & 0xffffffu) + (mlx & ((1u << lb) - 1u));
                         uint64_t offset;
                         if (ov > 3) {
                             offset = ov - 3;
@@ -833,9 +851,11 @@ __global__ __launch_bounds__(64) void zstd_kernel(BatchArgs a, int wlog_max)
                             }
                         }
                         if (i0 + j + 1 < nseq) {
-                            sl = (el >> 16) + sq_read(L, s, (el >> 8) & 0xffu);
-                            sm = (em >> 16) + sq_read(L, s, (em >> 8) & 0xffu);
-                            so = (eo >> 16) + sq_read(L, s, (eo >> 8) & 0xffu);
+                            const uint32_t nl = (el >> 8) & 0xffu, nm = (em >> 8) & 0xffu, no = (eo >> 8) & 0xffu;
+                            const uint32_t st3 = sq_read(L, s, nl + nm + no);  // <= 9 + 9 + 8 bits: LL, then ML, then OF
+                            sl = (el >> 16) + (st3 >> (nm + no));
+                            sm = (em >> 16) + ((st3 >> no) & ((1u << nm) - 1u));
+                            so = (eo >> 16) + (st3 & ((1u << no) - 1u));
                         }
                         if (s.avail < 0) {
                             dec_bad = j;
