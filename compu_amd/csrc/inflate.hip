@@ -6,10 +6,18 @@
 // wrappers with Adler-32 / CRC-32 verification (RFC 1950 / 1952).
 //
 // Data flow per wave:  compressed bytes --(coalesced dword loads)--> LDS input window
-//   --> canonical-Huffman LUTs in LDS --> token ring in LDS (literal | len,dist)
-//   --> wave prefix sum of token output lengths --> byte scatter of literals and cooperative
-//   LZ77 copies straight into the unit's output range in HBM (the window is the output itself,
-//   L2-resident for a 64 KiB unit).
+//   --> canonical-Huffman LUTs in LDS --> 64 lanes decode 64 segments of the bitstream at once, each
+//   from a guessed start, recording tokens (literal | len,dist) in the wave's scratch rows (HBM/L2)
+//   and joining the lane whose segment they run into --> the chain of joins from lane 0 is the true
+//   token stream --> wave prefix sum of token output lengths --> byte scatter of literals and
+//   cooperative LZ77 copies straight into the unit's output range in HBM (the window is the output
+//   itself, L2-resident for a 64 KiB unit).
+// The grid is persistent: waves take units from a counter, so the token scratch is one slot per
+// resident wave, not per unit.
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "chip_internal.h"
 #include "wave_checksums.h"
 
@@ -52,28 +60,25 @@ enum : int { T_CODES = 0, T_LENS = 1, T_DISTS = 2 };
 constexpr int LIT_ROOT = CHIP_LIT_ROOT;
 constexpr int DIST_ROOT = CHIP_DIST_ROOT;
 constexpr int CL_ROOT = 7;
-// Speculative wave-parallel decode geometry: per super-round lane i owns S_BITS of the stream
-// starting at B + i*S_BITS and decodes O_BITS further into its successor's range so that the point
-// where the two decodes fall into step (the merge) can be proven.  S_BITS is an odd number of
-// dwords so that the 64 lanes' window reads hit distinct LDS banks.
+// Speculative wave-parallel decode geometry: per super-round lane i walks the token chain that starts at
+// B + i*S_BITS (a guess, except for lane 0) and keeps walking past its own S_BITS segment until it steps
+// on a token boundary of the lane that owns the segment it is in (from there on the two chains are the
+// same), at most XT_BITS further.  Every lane records up to ROW_TOKENS tokens.  S_BITS is an odd number
+// of dwords so that the 64 lanes' window reads hit distinct LDS banks.
 #ifndef CHIP_S_BITS  // geometry overridable for experiments
-// measured on MI355X (round 1): 160/160 bits, an 864-token buffer and 9/8-bit root tables keep LDS at
-// 10.2 KB per wave (16 waves per CU = 4 per SIMD); larger super-rounds and tables have lower per-round
-// overheads and fewer long-code lookups but run at 7-11 waves per CU and lose
-#define CHIP_S_BITS 160
-#define CHIP_O_BITS 160
-#define CHIP_TOK_CAP 864
-#define CHIP_FIX_ROUNDS 12  // upper bound; the loop ends as soon as every live lane has merged
+#define CHIP_S_BITS 224
+#define CHIP_XT_BITS 1024
+#define CHIP_ROW_TOKENS 192
 #endif
 constexpr int S_BITS = CHIP_S_BITS;
-constexpr int O_BITS = CHIP_O_BITS;
-static_assert(O_BITS <= S_BITS && S_BITS % 32 == 0 && O_BITS % 32 == 0, "geometry");
-constexpr int BM_WORDS = (S_BITS + O_BITS) / 32;  // boundary bitmap words per lane
-constexpr int IN_DW = (31 + 64 * S_BITS + O_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
-constexpr int FIX_ROUNDS = CHIP_FIX_ROUNDS;  // restarts of lanes that did not merge, per super-round
-constexpr int TOK_CAP = CHIP_TOK_CAP;  // token buffer capacity (also holds the boundary bitmaps during pass 1)
-static_assert(BM_WORDS * 64 <= TOK_CAP, "bitmaps alias the token buffer");
-static_assert(IN_DW * 32 >= 31 + 63 * S_BITS + S_BITS + O_BITS + 48 + 96, "window covers every lane's reads");
+constexpr int XT_BITS = CHIP_XT_BITS;
+constexpr int ROW_TOKENS = CHIP_ROW_TOKENS;
+static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0, "geometry");
+constexpr int ROW_WORDS = S_BITS / 32;  // boundary bitmap words per lane (own segment only)
+constexpr int IN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
+static_assert(IN_DW >= 320, "table-build scratch lives in the input window");
+static_assert(ROW_TOKENS <= 256, "piece descriptors keep the row index in 8 bits");
+constexpr size_t SCRATCH_WORDS_PER_WAVE = (size_t)64 * ROW_TOKENS;
 
 // token: [8:0] match length (0 = literal), [31:9] literal byte or match distance
 __device__ __forceinline__ uint32_t tok_lit(uint32_t b) { return b << 9; }
@@ -92,8 +97,9 @@ struct alignas(16) WaveLds {
     uint32_t dist_sorted[32];
     uint32_t inbuf[IN_DW];
     union {
-        uint32_t tok[TOK_CAP + 192];  // tokens (and pass-1 bitmaps), then 192 words of copy-phase scratch
-        struct {                      // block-header scratch: only live while no tokens are buffered
+        uint32_t rows[ROW_WORDS * 64];  // [word][lane]: token boundaries each lane's chain has in its own segment
+        uint32_t piece_starts[2 * ROW_TOKENS];  // after the walk: bit t set = a piece of the true stream starts at token t
+        struct {                        // block-header scratch: only live between super-rounds
             uint32_t cl_lut[1 << CL_ROOT];
             uint32_t cl_sorted[20];
             HuffMeta cl_h;
@@ -101,6 +107,9 @@ struct alignas(16) WaveLds {
             uint8_t lens[320];
         } hdr;
     };
+    uint32_t fl_heads[64];  // copy phase: owner rank+1 per match byte of a step (also path-resolve flags)
+    uint32_t fl_par[128];   // copy phase: per-match parameters by rank (also path-resolve start indices)
+    uint32_t pk[64];        // k-th piece of the true stream: first row index | row (lane) << 8 | first stream index << 14
     HuffMeta lit_h, dist_h;
     uint32_t use_sub;  // long codes resolve through sub-tables living in lit_sorted/dist_sorted
 };
@@ -449,11 +458,25 @@ __device__ __forceinline__ void drain_copy(PendingCopy &pc, uint8_t *gout, uint3
     }
 }
 
-// LZ77 execution of tok[0..ntok): wave prefix sums give every token its output position; literals
+// Tokens g..g+63 of the super-round's true stream, one per lane.  The stream is a sequence of pieces,
+// each a run of one lane's scratch row; `before` = pieces that start ahead of token g.
+__device__ __forceinline__ uint32_t fetch_tokens(const WaveLds &L, const uint32_t *grow, uint32_t g, uint32_t ntok, uint32_t &before)
+{
+    const uint32_t gi = g >> 6;
+    const uint64_t m = (uint64_t)L.piece_starts[2 * gi] | ((uint64_t)L.piece_starts[2 * gi + 1] << 32);
+    const uint32_t k = before + (uint32_t)__popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1u;
+    before += (uint32_t)__popcll(m);
+    const uint32_t t = g + lane_id();
+    if (t >= ntok) return 0u;
+    const uint32_t d = L.pk[k];
+    return grow[((d >> 8) & 63u) * ROW_TOKENS + (d & 255u) + (t - (d >> 14))];
+}
+
+// LZ77 execution of the ntok tokens of the true stream: wave prefix sums give every token its output position; literals
 // are scattered with one byte store per 64 tokens; matches are copied several at a time, one
 // output byte per lane, as long as no source range reaches into bytes the same step writes.
 // Returns false when decoding must stop (error / output full).
-__device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status STAT_PARAM)
+__device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     PendingCopy pc;
@@ -465,11 +488,14 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
         pc.byte[j] = 0;
         pc.has[j] = false;
     }
+    uint32_t before = 0;
+    uint32_t t_next = fetch_tokens(L, grow, 0, ntok, before);
     for (uint32_t g = 0; g < ntok; g += 64) {
         STAT_ADD(13, 1);
         uint32_t i = g + lane;
         bool valid = i < ntok;
-        uint32_t t = valid ? L.tok[i] : 0u;
+        uint32_t t = t_next;
+        t_next = g + 64 < ntok ? fetch_tokens(L, grow, g + 64, ntok, before) : 0u;  // in flight while this group is executed
         uint32_t len = t & 0x1ffu, val = t >> 9;
         uint32_t olen = valid ? (len ? len : 1u) : 0u;
         uint32_t incl = wave_incl_scan(olen);
@@ -502,8 +528,8 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
             uint32_t mbi = wave_incl_scan(mlen);  // match bytes up to and including this match
             uint32_t mbx = mbi - mlen;
             uint32_t srcend = start - val + (len < val ? len : val);  // end of the bytes actually read
-            uint32_t *const fl_heads = &L.tok[TOK_CAP];        // 64 words: owner rank+1 per match byte of a step
-            uint32_t *const fl_par = &L.tok[TOK_CAP + 64];     // 64 x 2 words: per-match parameters by rank
+            uint32_t *const fl_heads = L.fl_heads;
+            uint32_t *const fl_par = L.fl_par;
             while (mm) {
                 STAT_ADD(14, 1);
                 const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
@@ -610,8 +636,6 @@ __device__ bool flush_tokens(WaveLds &L, uint32_t ntok, uint8_t *gout, uint32_t 
 
 // ---- per-lane token decode (lanes are at different bit positions) ---------------------------------
 
-// total bits of the token starting at `pos` (pass 1: boundaries only).  End-of-block and invalid
-// codes count as their code length so that a lane decoding from a guessed start just keeps going.
 // resolve a root entry that marks a code longer than the root table
 template <int ROOT>
 __device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, uint32_t e, uint32_t bits, const LongCodes<ROOT> &lc,
@@ -621,36 +645,20 @@ __device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, u
     return long_lookup<ROOT>(lc, sorted, __brev(bits) >> 17);
 }
 
-__device__ __forceinline__ uint32_t token_bits(const WaveLds &L, const InWin &w, uint32_t pos, const LongCodes<LIT_ROOT> &lcl,
-                                               const LongCodes<DIST_ROOT> &lcd, bool use_sub)
-{
-    // straight-line on purpose: the distance lookup runs for every lane (a literal lane just ignores it),
-    // which costs no extra issue slots and saves the exec-mask bookkeeping of a divergent branch
-    uint32_t lo, hi;
-    win_bits(L, w, pos, lo, hi);
-    uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-    if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
-    const uint32_t n1 = (e & 15u) + ((e >> 4) & 15u);
-    const bool islen = ((e >> 8) & 3u) == K_LEN;
-    const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-    uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-    if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
-    return n1 + (islen ? (e2 & 15u) + ((e2 >> 4) & 15u) : 0u);
-}
-
-enum : uint32_t { LS_NONE = 0, LS_EOB = 1, LS_NEED_INPUT = 2, LS_BAD = 3 };
+// why a lane stopped walking
+enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
 
 // Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them
 // into gout as it goes.  On return `pos` is behind the end-of-block code (status stays
 // ST_RUNNING) or status holds the reason decoding stopped.
 __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                             const uint32_t cap, int32_t &status STAT_PARAM)
+                             const uint32_t cap, int32_t &status, uint32_t *grow STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     const LongCodes<LIT_ROOT> lcl = load_long_codes<LIT_ROOT>(L.lit_h);
     const LongCodes<DIST_ROOT> lcd = load_long_codes<DIST_ROOT>(L.dist_h);
     const bool use_sub = rdfirst(L.use_sub) != 0;
-    uint32_t *bm = L.tok;  // [word][lane] boundary bitmaps, dead before the tokens are written
+    uint32_t *const myrow = grow + lane * ROW_TOKENS;
     for (;;) {
         const uint32_t B = pos;
         if (B >= end_bit) {
@@ -659,173 +667,133 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         }
         STAT_T0();
         win_load(L, w, B >> 5);
+#pragma unroll
+        for (int k = 0; k < ROW_WORDS; k++) L.rows[k * 64 + lane] = 0;
+        WSYNC();
         STAT_ACC(1);
         STAT_ADD(8, 1);
+        // ---- walk: every lane decodes from its guessed start until it joins another lane's chain ----
         const uint32_t s = B + lane * S_BITS;
-        uint32_t limit = s + S_BITS + O_BITS;
-        if (limit > end_bit) limit = end_bit;
-        // ---- pass 1: every lane walks token boundaries from its guessed start ------------------
-#pragma unroll
-        for (int k = 0; k < BM_WORDS; k++) bm[k * 64 + lane] = 0;
-        uint32_t p = s;
-        bool active = s < limit;
+        uint32_t lim = s + S_BITS + XT_BITS;
+        if (lim > B + 64u * S_BITS) lim = B + 64u * S_BITS;  // nobody to join behind the last segment
+        uint32_t p = s, nst = 0, reason = R_LIMIT, jl = 64, aux = s;
+        bool active = s < end_bit;
         while (__any(active)) {
             STAT_ADD(11, 1);
-            const uint32_t rel = p - s;
-            if (active) atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-            const uint32_t tb = token_bits(L, w, p, lcl, lcd, use_sub);  // finished lanes idle at their last boundary
-            p += active ? tb : 0u;
-            active = active && p < limit;
+            uint32_t t4[4];
+            const uint32_t q0 = nst;
+            const bool was = active;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                // the boundary at p: marked in the lane's own row, looked up in the row of the segment's owner elsewhere
+                const uint32_t rel = active ? p - B : lane * S_BITS;
+                const uint32_t seg = rel / S_BITS, off = rel - seg * S_BITS;
+                const uint32_t bit = 1u << (off & 31u);
+                const uint32_t old = atomicOr(&L.rows[(off >> 5) * 64 + seg], (active && seg == lane) ? bit : 0u);
+                const bool joined = active && seg != lane && (old & bit);
+                // straight-line token decode: the distance lookup runs for every lane (a literal lane just ignores
+                // it), which costs no extra issue slots and saves the exec-mask bookkeeping of a divergent branch
+                uint32_t lo, hi;
+                win_bits(L, w, p, lo, hi);
+                uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
+                if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
+                const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+                const uint32_t n1 = cl + eb;
+                const bool islen = kind == K_LEN;
+                const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+                uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
+                if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
+                const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
+                const uint32_t tb = n1 + (islen ? cl2 + eb2 : 0u);
+                t4[j] = islen ? tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2)) : tok_lit(e >> 16);
+                // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
+                uint32_t st = R_RUN;
+                st = (kind == K_BAD || (islen && ((e2 >> 8) & 3u) == K_BAD)) ? (uint32_t)R_BAD : st;
+                st = kind == K_EOB ? (uint32_t)R_EOB : st;
+                st = p + tb > end_bit ? (uint32_t)R_NEED_INPUT : st;
+                st = joined ? (uint32_t)R_JOIN : st;
+                const bool go = active && st == R_RUN;
+                if (active && !go) {
+                    reason = st;
+                    jl = seg;
+                    aux = st == R_EOB ? p + cl : p;  // behind the end-of-block code / where the chains met
+                }
+                nst += go ? 1u : 0u;
+                p += go ? tb : 0u;
+                active = go && p < lim && nst < (uint32_t)ROW_TOKENS;
+                if (go && !active) aux = p;  // reason stays R_LIMIT: the chain simply ends here
+            }
+            if (was && nst > q0) *(uint4 *)(myrow + q0) = make_uint4(t4[0], t4[1], t4[2], t4[3]);
         }
-        uint32_t e_end = p;  // first boundary at or behind the lane's limit
-        WSYNC();
+        WSYNC();  // rows complete; token stores have landed (the barrier's release waits for them)
         STAT_ACC(2);
-        // ---- merge points: first boundary lane i shares with lane i-1 inside lane i's first O_BITS --
-        auto merge_point = [&]() -> uint32_t {
-            uint32_t r = 0xffffffffu;
+        // ---- the true stream: lane 0's chain, then the chain it joined from the join on, and so on ----
+        const uint32_t nxt = reason == R_JOIN ? jl : 64u;
+        uint32_t a_join = 0;  // index, in the joined lane's row, of the token that starts at the join
+        if (reason == R_JOIN) {
+            const uint32_t off = aux - B - jl * S_BITS;
 #pragma unroll
-            for (int k = O_BITS / 32 - 1; k >= 0; k--) {
-                uint32_t c = bm[(S_BITS / 32 + k) * 64 + lane - 1] & bm[k * 64 + lane];
-                if (c) r = s + 32u * k + (uint32_t)__ffs((int)c) - 1;
+            for (int k = 0; k < ROW_WORDS; k++) {
+                int nb = (int)off - 32 * k;
+                nb = nb < 0 ? 0 : (nb > 32 ? 32 : nb);
+                const uint32_t below = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+                a_join += __popc(L.rows[k * 64 + jl] & below);
             }
-            return r;
-        };
-        uint32_t m = 0xffffffffu;
-        if (lane == 0) m = B;
-        else if (s < end_bit) m = merge_point();
-        // ---- fix-up rounds: a lane that did not fall into step with its predecessor starts over at
-        // the predecessor's last boundary (consistent by construction); pairs next to a redone lane
-        // are checked again.  Consecutive misses resolve one per round.
-        for (int round = 0; round < FIX_ROUNDS; round++) {
-            const uint32_t prev_end = (uint32_t)__shfl_up((int)e_end, 1, 64);
-            const bool redo = lane > 0 && m == 0xffffffffu && prev_end < limit;
-            if (!__any(redo)) break;
-            STAT_ADD(15, 1);
-            if (redo) {
+        }
+        // lanes on the path from lane 0, by pointer doubling over the join links (links only point forward)
+        bool on = lane == 0;
+        uint32_t jump = nxt;
 #pragma unroll
-                for (int k = 0; k < BM_WORDS; k++) bm[k * 64 + lane] = 0;
-                p = prev_end;
-                m = prev_end;
-            }
-            active = redo;
-            while (__any(active)) {
-                STAT_ADD(11, 1);
-                const uint32_t rel = p - s;
-                if (active) atomicOr(&bm[(rel >> 5) * 64 + lane], 1u << (rel & 31u));
-                const uint32_t tb = token_bits(L, w, p, lcl, lcd, use_sub);
-                p += active ? tb : 0u;
-                active = active && p < limit;
-            }
-            if (redo) e_end = p;
+        for (int r = 0; r < 6; r++) {
+            L.fl_heads[lane] = 0;
             WSYNC();
-            const bool pred_redo = __shfl_up((int)redo, 1, 64) != 0;
-            if (lane > 0 && pred_redo && s < end_bit) m = merge_point();
+            if (on && jump < 64u) L.fl_heads[jump] = 1;
+            WSYNC();
+            on = on || L.fl_heads[lane] != 0;
+            const uint32_t j2 = (uint32_t)__shfl((int)jump, (int)(jump & 63u), 64);
+            jump = jump < 64u ? j2 : 64u;
+            WSYNC();
         }
+        if (on && nxt < 64u) L.fl_par[nxt] = a_join;
+        WSYNC();
+        const uint32_t a0 = lane == 0 ? 0u : L.fl_par[lane];
+        const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint64_t onm = __ballot(on);
+        const uint32_t lz = 63u - (uint32_t)__clzll((long long)onm);  // the piece the stream ends in
+        const uint32_t T = rdlane(incl, 63u);
+        const uint32_t rz = rdlane(reason, lz), az = rdlane(aux, lz);
+        // piece descriptors in stream order and the bitmap of their first tokens (the rows are dead now)
+        for (uint32_t k = lane; k < 2u * ((T + 63u) >> 6); k += 64) L.piece_starts[k] = 0;
+        WSYNC();
+        const uint64_t nonempty = __ballot(cnt != 0);
+        if (cnt) {
+            const uint32_t first = incl - cnt;
+            const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt());
+            L.pk[k] = a0 | (lane << 8) | (first << 14);
+            atomicOr(&L.piece_starts[first >> 5], 1u << (first & 31u));
+        }
+        WSYNC();
         STAT_ACC(3);
-        const uint64_t failm = __ballot(m == 0xffffffffu);
-        uint32_t V = failm ? (uint32_t)__ffsll((long long)failm) - 1 : 64u;  // lanes 0..V-1 are on the true chain from m on
-        // lane i owns the tokens that start in [m_i, m_{i+1}); the last valid lane runs to its chain end
-        uint32_t up = (uint32_t)__shfl_down((int)m, 1, 64);
-        if (lane + 1 >= V) up = e_end;
-        uint32_t n = 0;
-        if (lane < V) {
-            const uint32_t lo_rel = m - s;
-            uint32_t hi_rel = up - s;
-            if (hi_rel > (uint32_t)(S_BITS + O_BITS)) hi_rel = S_BITS + O_BITS;
-#pragma unroll
-            for (int k = 0; k < BM_WORDS; k++) {
-                uint32_t word = bm[k * 64 + lane];
-                int lo_b = (int)lo_rel - 32 * k, hi_b = (int)hi_rel - 32 * k;
-                lo_b = lo_b < 0 ? 0 : (lo_b > 32 ? 32 : lo_b);
-                hi_b = hi_b < 0 ? 0 : (hi_b > 32 ? 32 : hi_b);
-                uint32_t below_hi = hi_b >= 32 ? 0xffffffffu : ((1u << hi_b) - 1u);
-                uint32_t below_lo = lo_b >= 32 ? 0xffffffffu : ((1u << lo_b) - 1u);
-                n += __popc(word & below_hi & ~below_lo);
-            }
-        }
-        uint32_t incl = wave_incl_scan(n);
-        uint32_t base = incl - n;
-        // keep the longest prefix of lanes whose tokens fit the buffer
-        const uint64_t fitm = __ballot(lane < V && incl <= (uint32_t)TOK_CAP);
-        const uint32_t V2 = (uint32_t)__popcll(fitm);
-        uint32_t next_B = V2 < V ? rdlane(m, V2 & 63u) : rdlane(e_end, (V - 1) & 63u);
-        if (V2 < V) {
-            if (lane + 1 == V2) up = next_B;
-            V = V2;
-        }
-        WSYNC();
-        STAT_ADD(9, V);
-        // ---- pass 2: exact decode of the owned ranges, tokens written in stream order --------------
-        uint32_t k = 0, lstat = LS_NONE, stop_pos = 0;
-        p = m;
-        active = lane < V && n > 0;
-        while (__any(active)) {
-            STAT_ADD(12, 1);
-            // straight-line body (see token_bits); only the token store and the state updates are predicated
-            uint32_t lo, hi;
-            win_bits(L, w, p, lo, hi);
-            uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-            if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
-            const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
-            const uint32_t n1 = cl + eb;
-            const bool islen = kind == K_LEN;
-            const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-            uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-            if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
-            const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-            const uint32_t tb = n1 + (islen ? cl2 + eb2 : 0u);
-            const uint32_t token = islen ? tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2)) : tok_lit(e >> 16);
-            // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
-            uint32_t st = LS_NONE;
-            st = (kind == K_BAD || (islen && ((e2 >> 8) & 3u) == K_BAD)) ? (uint32_t)LS_BAD : st;
-            st = kind == K_EOB ? (uint32_t)LS_EOB : st;
-            st = p + tb > end_bit ? (uint32_t)LS_NEED_INPUT : st;
-            const bool go = active && st == LS_NONE;
-            if (go) L.tok[base + k] = token;
-            const bool stop = active && st != LS_NONE;
-            lstat = stop ? st : lstat;
-            stop_pos = stop ? p + cl : stop_pos;  // behind the end-of-block code
-            k += go ? 1u : 0u;
-            p += go ? tb : 0u;
-            active = go && k < n;
-        }
-        WSYNC();
-        const uint64_t stopm = __ballot(lstat != LS_NONE);
-        uint32_t T = rdlane(incl, (V - 1) & 63u);
-        uint32_t first_stat = LS_NONE, first_stop = 0;
-        if (stopm) {
-            const uint32_t E = (uint32_t)__ffsll((long long)stopm) - 1;
-            T = rdlane(base + k, E);
-            first_stat = rdlane(lstat, E);
-            first_stop = rdlane(stop_pos, E);
-        }
-        STAT_ACC(4);
+        STAT_ADD(9, __popcll(onm));
         STAT_ADD(10, T);
         int32_t st2 = ST_RUNNING;
-#ifdef CHIP_EXP_NOFLUSH
-        bool flushed = true;
-        opos += T;
-#else
-        bool flushed = flush_tokens(L, T, gout, opos, cap, st2 STAT_ARG);
-#endif
+        const bool flushed = flush_tokens(L, grow, T, gout, opos, cap, st2 STAT_ARG);
         STAT_ACC(20);
         if (!flushed) {
             status = st2;
             return;
         }
-        if (first_stat == LS_EOB) {
-            pos = first_stop;
-            return;
-        }
-        if (first_stat == LS_NEED_INPUT) {
+        if (rz == R_NEED_INPUT) {
             status = CHIP_NEED_INPUT;
             return;
         }
-        if (first_stat == LS_BAD) {
+        if (rz == R_BAD) {
             status = Z_DATA_ERROR;
             return;
         }
-        pos = next_B;
+        pos = az;
+        if (rz == R_EOB) return;
     }
 }
 
@@ -833,7 +801,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
 // After both alphabets are built: try to replace sorted[] by sub-tables (see build_subtables).
 __device__ void finish_tables(WaveLds &L)
 {
-    uint32_t *scratch = &L.tok[512];  // free: no tokens are buffered while tables are built
+    uint32_t *scratch = L.inbuf;  // free: the block header is parsed and decode_block stages its own window
     WSYNC();
     uint32_t n1 = build_subtables<LIT_ROOT>(L.lit_h, L.lit_sorted, L.lit_lut, scratch, 0);
     uint32_t n2 = n1 == 0xffffffffu ? n1 : build_subtables<DIST_ROOT>(L.dist_h, L.dist_sorted, L.dist_lut, scratch, n1);
@@ -849,13 +817,11 @@ __device__ void finish_tables(WaveLds &L)
 }
 
 #ifndef CHIP_WAVES_PER_SIMD
-#define CHIP_WAVES_PER_SIMD 1
+#define CHIP_WAVES_PER_SIMD 4
 #endif
-__global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchArgs a)
+// one unit, start to finish, by the calling wave; grow = the wave's token scratch rows
+__device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, uint32_t *grow)
 {
-    __shared__ WaveLds L;
-    const uint32_t u = blockIdx.x;
-    if (u >= a.n) return;
     const uint32_t lane = lane_id();
 
     const uint8_t *gin = a.in_base + a.in_off[u];
@@ -1064,7 +1030,7 @@ __global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchA
             finish_tables(L);
         }
         STAT_ACC(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status STAT_ARG);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status, grow STAT_ARG);
         STAT_T0();
     }
     STAT_ACC(0);
@@ -1106,10 +1072,65 @@ __global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchA
     }
 }
 
+// Persistent grid: each wave takes the next unit from *next_unit until the batch is exhausted.
+__global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchArgs a, uint32_t *scratch, uint32_t *next_unit)
+{
+    __shared__ WaveLds L;
+    uint32_t *grow = scratch + (size_t)blockIdx.x * SCRATCH_WORDS_PER_WAVE;
+    for (;;) {
+        uint32_t u = 0;
+        if (lane_id() == 0) u = atomicAdd(next_unit, 1u);
+        u = rdfirst(u);
+        if (u >= a.n) break;
+        inflate_unit(a, u, L, grow);
+        WSYNC();  // the next unit reuses the LDS
+    }
+}
+
+namespace {
+// Token scratch and the unit counter of a launch, cached per (device, stream): launches on one stream
+// run in order, so they can share a slot; different streams get their own.
+struct LaunchSlot {
+    uint32_t *scratch = nullptr;
+    uint32_t *counter = nullptr;
+    int blocks = 0;
+};
+std::mutex g_slot_mu;
+std::map<std::pair<int, hipStream_t>, LaunchSlot> g_slots;
+
+hipError_t slot_for(hipStream_t stream, LaunchSlot &out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    LaunchSlot &sl = g_slots[{dev, stream}];
+    if (!sl.scratch) {
+        int per_cu = 0, cus = 0;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inflate_kernel, 64, 0)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        const int blocks = per_cu * cus;
+        uint32_t *p = nullptr;
+        if ((e = hipMalloc((void **)&p, (size_t)blocks * SCRATCH_WORDS_PER_WAVE * 4 + 256)) != hipSuccess) return e;
+        sl.scratch = p;
+        sl.counter = p + (size_t)blocks * SCRATCH_WORDS_PER_WAVE;
+        sl.blocks = blocks;
+    }
+    out = sl;
+    return hipSuccess;
+}
+}  // namespace
+
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
-    hipLaunchKernelGGL(inflate_kernel, dim3(a.n), dim3(64), 0, stream, a);
+    LaunchSlot sl;
+    hipError_t e = slot_for(stream, sl);
+    if (e != hipSuccess) return e;
+    if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
+    const uint32_t blocks = a.n < (uint32_t)sl.blocks ? a.n : (uint32_t)sl.blocks;
+    hipLaunchKernelGGL(inflate_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
     return hipGetLastError();
 }
 
