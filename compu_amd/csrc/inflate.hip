@@ -98,7 +98,6 @@ struct alignas(16) WaveLds {
     uint32_t inbuf[IN_DW];
     union {
         uint32_t rows[ROW_WORDS * 64];  // [word][lane]: token boundaries each lane's chain has in its own segment
-        uint32_t piece_starts[2 * ROW_TOKENS];  // after the walk: bit t set = a piece of the true stream starts at token t
         struct {                        // block-header scratch: only live between super-rounds
             uint32_t cl_lut[1 << CL_ROOT];
             uint32_t cl_sorted[20];
@@ -438,199 +437,239 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
     return off - q * d;
 }
 
-// One copy step whose loads are in flight: its stores are issued only when the next step's loads
-// have been issued too (or when the next step reads what this one writes).
-struct PendingCopy {
-    uint32_t dst[4];
-    uint8_t byte[4];
-    bool has[4];
-    bool valid;
-    uint32_t d0;  // lowest destination of the step
+// ---- LZ77 execution -----------------------------------------------------------------------------
+// The true token stream of a super-round is executed a chunk at a time.  A chunk is up to CHUNK_TOKENS
+// tokens producing at most CHUNK_BYTES output bytes; its tokens, their output offsets and a bitmap of the
+// output bytes at which a token starts sit in LDS (in the input window and the boundary rows, both dead
+// until the next super-round).  The output is then produced 256 bytes per step, four consecutive bytes
+// per lane: the owner token of a byte is the number of token starts at or before it (bitmap prefix
+// popcount), a literal's byte comes from the token, a match byte is loaded from the output written
+// earlier, and each lane issues one dword store.
+constexpr uint32_t CHUNK_GROUPS = 5;
+constexpr uint32_t CHUNK_TOKENS = 64 * CHUNK_GROUPS;
+constexpr uint32_t CHUNK_BYTES = 2048;
+static_assert(CHUNK_TOKENS <= IN_DW, "chunk tokens live in the input window");
+static_assert(CHUNK_TOKENS / 2 + 3 * (CHUNK_BYTES / 32) + 2 <= ROW_WORDS * 64, "chunk offsets and bitmaps live in the boundary rows");
+
+struct ChunkLds {
+    uint32_t *tok;     // [CHUNK_TOKENS]
+    uint16_t *start;   // [CHUNK_TOKENS] output offset of the token, relative to the chunk's dword-aligned base
+    uint32_t *heads;   // [CHUNK_BYTES / 32] bit x set = a token starts at offset x
+    uint32_t *wpre;    // [CHUNK_BYTES / 32] token starts in all lower words
+    uint32_t *haz;     // [CHUNK_BYTES / 32] bit x set = the match starting at x reads bytes less than 260 below x
+    uint32_t *pmask;   // [2] gather scratch: piece starts inside a 64-token group
 };
 
-__device__ __forceinline__ void drain_copy(PendingCopy &pc, uint8_t *gout, uint32_t cap)
+__device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
 {
-    if (pc.valid) {
+    ChunkLds c;
+    c.tok = L.inbuf;
+    c.start = (uint16_t *)L.rows;
+    c.heads = L.rows + CHUNK_TOKENS / 2;
+    c.wpre = c.heads + CHUNK_BYTES / 32;
+    c.haz = c.wpre + CHUNK_BYTES / 32;
+    c.pmask = c.haz + CHUNK_BYTES / 32;
+    return c;
+}
+
+// four consecutive output bytes of a step: one dword store when the lane produced all four
+__device__ __forceinline__ void emit_step(uint8_t *base, uint32_t x0, uint32_t word, uint32_t mask)
+{
+#ifndef CHIP_EXP_NOSTORE
+    if (mask == 15u) {
+        *(uint32_t *)(base + x0) = word;
+    } else if (mask) {
 #pragma unroll
         for (int j = 0; j < 4; j++)
-            if (pc.has[j] && pc.dst[j] < cap) gout[pc.dst[j]] = pc.byte[j];
-        pc.valid = false;
+            if ((mask >> j) & 1u) base[x0 + j] = (uint8_t)(word >> (8 * j));
     }
+#endif
 }
 
-// Tokens g..g+63 of the super-round's true stream, one per lane.  The stream is a sequence of pieces,
-// each a run of one lane's scratch row; `before` = pieces that start ahead of token g.
-__device__ __forceinline__ uint32_t fetch_tokens(const WaveLds &L, const uint32_t *grow, uint32_t g, uint32_t ntok, uint32_t &before)
-{
-    const uint32_t gi = g >> 6;
-    const uint64_t m = (uint64_t)L.piece_starts[2 * gi] | ((uint64_t)L.piece_starts[2 * gi + 1] << 32);
-    const uint32_t k = before + (uint32_t)__popcll(m & (lanemask_lt() | (1ull << lane_id()))) - 1u;
-    before += (uint32_t)__popcll(m);
-    const uint32_t t = g + lane_id();
-    if (t >= ntok) return 0u;
-    const uint32_t d = L.pk[k];
-    return grow[((d >> 8) & 63u) * ROW_TOKENS + (d & 255u) + (t - (d >> 14))];
-}
-
-// LZ77 execution of the ntok tokens of the true stream: wave prefix sums give every token its output position; literals
-// are scattered with one byte store per 64 tokens; matches are copied several at a time, one
-// output byte per lane, as long as no source range reaches into bytes the same step writes.
+// Executes the ntok tokens of the true stream (npieces pieces described by L.pk) into gout at opos.
 // Returns false when decoding must stop (error / output full).
-__device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, uint8_t *gout, uint32_t &opos, uint32_t cap, int32_t &status STAT_PARAM)
+__device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, uint32_t npieces, uint8_t *gout, uint32_t &opos,
+                             uint32_t cap, int32_t &status STAT_PARAM)
 {
     const uint32_t lane = lane_id();
-    PendingCopy pc;
-    pc.valid = false;
-    pc.d0 = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        pc.dst[j] = 0;
-        pc.byte[j] = 0;
-        pc.has[j] = false;
-    }
-    uint32_t before = 0;
-    uint32_t t_next = fetch_tokens(L, grow, 0, ntok, before);
-    for (uint32_t g = 0; g < ntok; g += 64) {
+    const ChunkLds C = chunk_lds(L);
+    const uint64_t le_mask = lanemask_lt() | (1ull << lane);
+    const uint32_t pfirst = lane < npieces ? L.pk[lane] >> 14 : 0xffffffffu;  // first stream index of piece `lane`
+    uint32_t c0 = 0;  // tokens executed so far
+    while (c0 < ntok) {
         STAT_ADD(13, 1);
-        uint32_t i = g + lane;
-        bool valid = i < ntok;
-        uint32_t t = t_next;
-        t_next = g + 64 < ntok ? fetch_tokens(L, grow, g + 64, ntok, before) : 0u;  // in flight while this group is executed
-        uint32_t len = t & 0x1ffu, val = t >> 9;
-        uint32_t olen = valid ? (len ? len : 1u) : 0u;
-        uint32_t incl = wave_incl_scan(olen);
-        uint32_t start = opos + incl - olen;
-        // "invalid distance too far back": distance reaches before the first output byte
-        uint64_t badm = __ballot(valid && len && val > start);
-        int32_t err = 0;
-        uint32_t total;
-        if (badm) {
-            uint32_t fb = (uint32_t)__ffsll((long long)badm) - 1;
-            if (lane >= fb) {
-                valid = false;
-                len = 0;
+        // ---- gather: token c0 + 64 j + lane -> tmp[j]; the piece a token lies in = pieces that start at or before it
+        uint32_t tmp[CHUNK_GROUPS];
+        WSYNC();  // the previous chunk's LDS reads are done
+#pragma unroll
+        for (uint32_t j = 0; j < CHUNK_GROUPS; j++) {
+            const uint32_t g = c0 + 64u * j;
+            tmp[j] = 0;
+            if (g < ntok) {
+                if (lane < 2) C.pmask[lane] = 0;
+                WSYNC();
+                const uint32_t rel = pfirst - g;
+                if (rel < 64u) atomicOr(&C.pmask[rel >> 5], 1u << (rel & 31u));
+                WSYNC();
+                const uint64_t m = (uint64_t)C.pmask[0] | ((uint64_t)C.pmask[1] << 32);
+                const uint32_t before = (uint32_t)__popcll(__ballot(pfirst < g));
+                uint32_t k = before + (uint32_t)__popcll(m & le_mask) - 1u;
+                k = k < 64u ? k : 63u;
+                uint32_t t = g + lane;
+                t = t < ntok ? t : ntok - 1u;  // lanes behind the end re-read the last token: no branch around the load
+                const uint32_t d = L.pk[k];
+                tmp[j] = grow[((d >> 8) & 63u) * ROW_TOKENS + (d & 255u) + (t - (d >> 14))];
             }
-            total = rdlane(start, fb) - opos;
-            err = Z_DATA_ERROR;
-        } else {
-            total = rdlane(incl, 63u);
         }
-#ifndef CHIP_EXP_NOLIT
-        if (valid && !len && start < cap) gout[start] = (uint8_t)val;
-#endif
-        uint32_t mlen = (valid && len) ? len : 0u;
-        uint64_t mm = __ballot(mlen != 0);
-#ifdef CHIP_EXP_NOMATCH
-        mm = 0;
-#endif
+        // ---- chunk setup: output offsets (relative to the dword-aligned address below the chunk's first byte)
+        const uint32_t mis = (uint32_t)((uintptr_t)(gout + opos) & 3u);
+        uint8_t *const base = gout + opos - mis;  // byte x of the chunk lives at base[x]; base is dword aligned
+        C.heads[lane] = 0;
+        C.haz[lane] = 0;
+        WSYNC();
+        uint32_t run = mis, nc = 0;
+        bool too_far = false;
+#pragma unroll
+        for (uint32_t j = 0; j < CHUNK_GROUPS; j++) {
+            const uint32_t g = c0 + 64u * j;
+            if (g >= ntok) break;
+            const bool valid = g + lane < ntok;
+            const uint32_t t = tmp[j];
+            const uint32_t len = t & 0x1ffu, val = t >> 9;
+            const uint32_t olen = valid ? (len ? len : 1u) : 0u;
+            const uint32_t incl = wave_incl_scan(olen);
+            const uint32_t start = run + incl - olen;
+            const bool fits = run + incl <= CHUNK_BYTES;
+            // "invalid distance too far back": the distance reaches before the first output byte
+            const bool bad = len && val > opos + start - mis;
+            const uint64_t stopm = __ballot(valid && (!fits || bad));
+            const uint32_t nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : (uint32_t)__popcll(__ballot(valid));
+            if (lane < nacc) {
+                C.tok[64u * j + lane] = t;
+                C.start[64u * j + lane] = (uint16_t)start;
+                atomicOr(&C.heads[start >> 5], 1u << (start & 31u));
+                // a step is at most 259 bytes: only a match whose source ends less than that below its start can
+                // ever read what its own step has yet to write
+                if (len && val < 260u + (len < val ? len : val)) atomicOr(&C.haz[start >> 5], 1u << (start & 31u));
+            }
+            nc += nacc;
+            if (stopm) {
+                too_far = rdlane(bad ? 1u : 0u, nacc) != 0 && rdlane(fits ? 1u : 0u, nacc) != 0;
+                run = rdlane(start, nacc);
+                break;
+            }
+            run = rdlane(run + incl, 63u);
+            if (nacc < 64u) break;
+        }
+        const uint32_t xend = run;  // offsets [mis, xend) are produced by this chunk
+        WSYNC();
+        {
+            const uint32_t hw = C.heads[lane];
+            const uint32_t pc = (uint32_t)__popc(hw);
+            C.wpre[lane] = wave_incl_scan(pc) - pc;
+        }
+        WSYNC();
         STAT_ACC(16);
-        if (mm) {
-            uint32_t mbi = wave_incl_scan(mlen);  // match bytes up to and including this match
-            uint32_t mbx = mbi - mlen;
-            uint32_t srcend = start - val + (len < val ? len : val);  // end of the bytes actually read
-            uint32_t *const fl_heads = L.fl_heads;
-            uint32_t *const fl_par = L.fl_par;
-            while (mm) {
-                STAT_ADD(14, 1);
-                const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
-                const uint32_t d0 = rdlane(start, k0), b0 = rdlane(mbx, k0), l0 = rdlane(mlen, k0);
-                if (d0 >= cap) break;  // everything from here on lies behind the output capacity
-                if (l0 > 256) {
-                    drain_copy(pc, gout, cap);
-                    // a single very long match: lanes stride over it; a period shorter than the length repeats
-                    const uint32_t ds = rdlane(val, k0);
-                    const uint8_t *src = gout + (d0 - ds);
-                    for (uint32_t j = lane; j < l0; j += 64) {
-                        uint32_t so = ds >= l0 ? j : small_mod(j, ds);
-                        uint8_t b = src[so];
-                        if (d0 + j < cap) gout[d0 + j] = b;
-                    }
-                    mm &= mm - 1;
-                    continue;
-                }
-                // longest run of matches from k0 that fits 256 bytes and reads nothing this step writes
-                const uint64_t okm = __ballot(mlen && (mbi - b0 <= 256u) && (lane == k0 || srcend <= d0));
-                const uint64_t rem = mm & ~okm;
-                const uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
-                const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
-                const uint32_t nbytes = rdlane(mbi, lastl) - b0;
-                STAT_ACC(17);
-                // owner of every match byte: heads scattered by rank, then a running maximum
-                fl_heads[lane] = 0;
-                const bool mine = (inc >> lane) & 1ull;
-                if (mine) {
-                    const uint32_t rank = (uint32_t)__popcll(inc & lanemask_lt());
-                    const uint32_t rel = mbx - b0;
-                    ((uint8_t *)fl_heads)[rel] = (uint8_t)(rank + 1);
-                    fl_par[2 * rank] = start;
-                    fl_par[2 * rank + 1] = val | ((mlen - 1u) << 16) | (rel << 24);
-                }
-                WSYNC();  // other lanes' scatter must be visible (and not forwarded past) before the reads
-                const uint32_t h = fl_heads[lane];
-                uint32_t r0 = h & 0xffu, r1 = (h >> 8) & 0xffu, r2 = (h >> 16) & 0xffu, r3 = h >> 24;
-                r1 = r1 > r0 ? r1 : r0;
-                r2 = r2 > r1 ? r2 : r1;
-                r3 = r3 > r2 ? r3 : r2;
-                const uint32_t carry = wave_shr1(wave_incl_max_scan(r3));
-                r0 = r0 > carry ? r0 : carry;
-                r1 = r1 > carry ? r1 : carry;
-                r2 = r2 > carry ? r2 : carry;
-                r3 = r3 > carry ? r3 : carry;
-                const uint32_t rr[4] = {r0, r1, r2, r3};
-                uint32_t srcs[4], dsts[4];
-                bool has[4];
+        // ---- steps
+        uint32_t lo = mis;  // everything below is already in memory
+        bool pend_any = false;  // a step whose bytes are assembled but not stored yet
+        uint32_t pend_x0 = 0, pend_word = 0, pend_mask = 0, pend_lo = 0x7fffffffu;
+        while (lo < xend) {
+            STAT_ADD(14, 1);
+            const uint32_t x0 = (lo & ~3u) + 4u * lane;
+            const uint32_t wi = x0 >> 5, sh = x0 & 31u;
+            const bool inmap = wi < CHUNK_BYTES / 32;
+            const uint32_t hw = inmap ? C.heads[wi] : 0u, wp = inmap ? C.wpre[wi] : 0u, hz = inmap ? (C.haz[wi] >> sh) & 15u : 0u;
+            uint32_t r[4], tk[4], st[4];
 #pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t q = 4u * lane + j;
-                    has[j] = q < nbytes;
-                    const uint32_t r = (has[j] && rr[j]) ? rr[j] - 1u : 0u;
-                    const uint32_t st = fl_par[2 * r], pv = fl_par[2 * r + 1];
-                    const uint32_t ds = pv & 0xffffu, ln = ((pv >> 16) & 0xffu) + 1u, off = q - (pv >> 24);
-                    dsts[j] = st + off;
-                    srcs[j] = st - ds + (ds >= ln ? off : small_mod(off, ds));
-                }
-                WSYNC();  // every lane has read the scratch before the next step rewrites it
-                STAT_ACC(18);
-                // software pipeline: this step's loads go out before the previous step's stores unless
-                // this step reads bytes the previous one writes
-#ifdef CHIP_EXP_NOMEM
-                uint8_t bytes[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) bytes[j] = (uint8_t)(srcs[j] ^ dsts[j]);
-                if (nbytes == 0xdeadbeef) drain_copy(pc, gout, cap);
-#else
-                if (pc.valid && __any(mine && srcend > pc.d0)) drain_copy(pc, gout, cap);
-                uint8_t bytes[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) bytes[j] = gout[has[j] ? srcs[j] : 0u];  // lanes without a byte re-read byte 0
-                drain_copy(pc, gout, cap);
-#endif
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    pc.dst[j] = dsts[j];
-                    pc.byte[j] = bytes[j];
-                    pc.has[j] = has[j];
-                }
-                pc.valid = true;
-                pc.d0 = d0;
-                mm &= ~inc;
-                STAT_ACC(19);
+            for (int j = 0; j < 4; j++) {
+                const uint32_t n = wp + (uint32_t)__popc(hw & ((2u << (sh + j)) - 1u));  // token starts at or below x0 + j
+                r[j] = n ? (n <= CHUNK_TOKENS ? n - 1u : CHUNK_TOKENS - 1u) : 0u;
             }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                tk[j] = C.tok[r[j]];
+                st[j] = C.start[r[j]];
+            }
+            // the step ends 256 bytes behind its dword-aligned start, at the chunk end, or at the first match
+            // that starts behind lo and reads bytes at or above lo
+            uint32_t e = (lo & ~3u) + 256u;
+            e = e < xend ? e : xend;
+            if (__any(hz != 0)) {
+                uint32_t first_conf = 0xffffffffu;
+#pragma unroll
+                for (int j = 3; j >= 0; j--) {
+                    const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
+                    const uint32_t srcend = st[j] - val + (len < val ? len : val);
+                    const bool conf = ((hz >> j) & 1u) && st[j] > lo && (int32_t)srcend > (int32_t)lo;
+                    first_conf = conf ? x0 + j : first_conf;
+                }
+                const uint64_t cm = __ballot(first_conf != 0xffffffffu);
+                if (cm) {
+                    const uint32_t fc = rdlane(first_conf, (uint32_t)__ffsll((long long)cm) - 1u);
+                    e = fc < e ? fc : e;
+                }
+            }
+            uint32_t byte[4], srcx[4];
+            bool want[4], isld[4];
+            const uint32_t xcap = cap - (opos - mis);  // offsets at or above lie behind the output capacity
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t x = x0 + j;
+                const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
+                const uint32_t off = x - st[j];
+                const uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)val));  // off / val for off, val < 512
+                srcx[j] = st[j] - val + (val >= len ? off : off - q * val);
+                want[j] = (x >= lo) & (x < e) & (x < xcap);
+                isld[j] = want[j] & (len != 0);
+                byte[j] = val & 0xffu;
+            }
+            // all four loads go out before any is waited for
+            // Software pipeline: this step's loads are issued before the previous step's store, so waiting for the
+            // loads does not wait for that store (memory operations retire in issue order) -- unless this step reads
+            // what the previous one wrote.
+            uint32_t dep = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) dep |= (isld[j] && (int32_t)srcx[j] >= (int32_t)pend_lo) ? 1u : 0u;
+            if (pend_any && __any(dep != 0)) {
+                emit_step(base, pend_x0, pend_word, pend_mask);
+                pend_any = false;
+                pend_mask = 0;
+            }
+            uint8_t ld[4] = {0, 0, 0, 0};
+#ifndef CHIP_EXP_NOLOAD
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (isld[j]) ld[j] = base[(int32_t)srcx[j]];
+#endif
+            if (pend_any) emit_step(base, pend_x0, pend_word, pend_mask);
+            pend_word = 0;
+            pend_mask = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                byte[j] = isld[j] ? (uint32_t)ld[j] : byte[j];
+                pend_word |= byte[j] << (8 * j);
+                pend_mask |= want[j] ? 1u << j : 0u;
+            }
+            pend_x0 = x0;
+            pend_lo = lo;
+            pend_any = true;
+            lo = e;
         }
-        opos += total;
+        if (pend_any) emit_step(base, pend_x0, pend_word, pend_mask);
+        STAT_ACC(17);
+        opos += xend - mis;
+        c0 += nc;
         if (opos > cap) {
-            drain_copy(pc, gout, cap);
             opos = cap;
             status = CHIP_NEED_OUTPUT;
             return false;
         }
-        if (err) {
-            drain_copy(pc, gout, cap);
-            status = err;
+        if (too_far) {
+            status = Z_DATA_ERROR;
             return false;
         }
     }
-    drain_copy(pc, gout, cap);
     return true;
 }
 
@@ -763,22 +802,16 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         const uint32_t lz = 63u - (uint32_t)__clzll((long long)onm);  // the piece the stream ends in
         const uint32_t T = rdlane(incl, 63u);
         const uint32_t rz = rdlane(reason, lz), az = rdlane(aux, lz);
-        // piece descriptors in stream order and the bitmap of their first tokens (the rows are dead now)
-        for (uint32_t k = lane; k < 2u * ((T + 63u) >> 6); k += 64) L.piece_starts[k] = 0;
-        WSYNC();
+        // piece descriptors in stream order
         const uint64_t nonempty = __ballot(cnt != 0);
-        if (cnt) {
-            const uint32_t first = incl - cnt;
-            const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt());
-            L.pk[k] = a0 | (lane << 8) | (first << 14);
-            atomicOr(&L.piece_starts[first >> 5], 1u << (first & 31u));
-        }
+        if (cnt) L.pk[__popcll(nonempty & lanemask_lt())] = a0 | (lane << 8) | ((incl - cnt) << 14);
         WSYNC();
         STAT_ACC(3);
         STAT_ADD(9, __popcll(onm));
         STAT_ADD(10, T);
         int32_t st2 = ST_RUNNING;
-        const bool flushed = flush_tokens(L, grow, T, gout, opos, cap, st2 STAT_ARG);
+        const bool flushed = flush_tokens(L, grow, T, (uint32_t)__popcll(nonempty), gout, opos, cap, st2 STAT_ARG);
+        w.win0 = 0xffffffffu;  // the flush used the window as its token buffer
         STAT_ACC(20);
         if (!flushed) {
             status = st2;
