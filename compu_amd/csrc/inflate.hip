@@ -14,6 +14,7 @@
 //   itself, L2-resident for a 64 KiB unit).
 // The grid is persistent: waves take units from a counter, so the token scratch is one slot per
 // resident wave, not per unit.
+#include <cstddef>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -444,12 +445,14 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 // until the next super-round).  The output is then produced 256 bytes per step, four consecutive bytes
 // per lane: the owner token of a byte is the number of token starts at or before it (bitmap prefix
 // popcount), a literal's byte comes from the token, a match byte is loaded from the output written
-// earlier, and each lane issues one dword store.
-constexpr uint32_t CHUNK_GROUPS = 5;
+// earlier -- from the chunk's own output, which is assembled in LDS, or from HBM when the source lies
+// below the chunk -- and the finished chunk goes out with coalesced dword stores.
+constexpr uint32_t CHUNK_GROUPS = 4;
 constexpr uint32_t CHUNK_TOKENS = 64 * CHUNK_GROUPS;
-constexpr uint32_t CHUNK_BYTES = 2048;
-static_assert(CHUNK_TOKENS <= IN_DW, "chunk tokens live in the input window");
-static_assert(CHUNK_TOKENS / 2 + 3 * (CHUNK_BYTES / 32) + 2 <= ROW_WORDS * 64, "chunk offsets and bitmaps live in the boundary rows");
+constexpr uint32_t CHUNK_BYTES = 1024;
+constexpr uint32_t CHUNK_LDS_WORDS = CHUNK_TOKENS + CHUNK_TOKENS / 2 + 3 * (CHUNK_BYTES / 32) + 2 + CHUNK_BYTES / 4 + 2;
+static_assert(CHUNK_LDS_WORDS <= IN_DW + ROW_WORDS * 64, "the chunk state lives in the input window and the boundary rows");
+static_assert(CHUNK_BYTES / 32 <= 64, "one wave scan covers the bitmap words");
 
 struct ChunkLds {
     uint32_t *tok;     // [CHUNK_TOKENS]
@@ -458,32 +461,21 @@ struct ChunkLds {
     uint32_t *wpre;    // [CHUNK_BYTES / 32] token starts in all lower words
     uint32_t *haz;     // [CHUNK_BYTES / 32] bit x set = the match starting at x reads bytes less than 260 below x
     uint32_t *pmask;   // [2] gather scratch: piece starts inside a 64-token group
+    uint32_t *out;     // [CHUNK_BYTES / 4 + 2] the chunk's output bytes by offset
 };
 
 __device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
 {
+    static_assert(offsetof(WaveLds, rows) == offsetof(WaveLds, inbuf) + sizeof(uint32_t) * IN_DW, "window and rows are contiguous");
     ChunkLds c;
     c.tok = L.inbuf;
-    c.start = (uint16_t *)L.rows;
-    c.heads = L.rows + CHUNK_TOKENS / 2;
+    c.start = (uint16_t *)(c.tok + CHUNK_TOKENS);
+    c.heads = c.tok + CHUNK_TOKENS + CHUNK_TOKENS / 2;
     c.wpre = c.heads + CHUNK_BYTES / 32;
     c.haz = c.wpre + CHUNK_BYTES / 32;
     c.pmask = c.haz + CHUNK_BYTES / 32;
+    c.out = c.pmask + 2;
     return c;
-}
-
-// four consecutive output bytes of a step: one dword store when the lane produced all four
-__device__ __forceinline__ void emit_step(uint8_t *base, uint32_t x0, uint32_t word, uint32_t mask)
-{
-#ifndef CHIP_EXP_NOSTORE
-    if (mask == 15u) {
-        *(uint32_t *)(base + x0) = word;
-    } else if (mask) {
-#pragma unroll
-        for (int j = 0; j < 4; j++)
-            if ((mask >> j) & 1u) base[x0 + j] = (uint8_t)(word >> (8 * j));
-    }
-#endif
 }
 
 // Executes the ntok tokens of the true stream (npieces pieces described by L.pk) into gout at opos.
@@ -524,8 +516,10 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
         // ---- chunk setup: output offsets (relative to the dword-aligned address below the chunk's first byte)
         const uint32_t mis = (uint32_t)((uintptr_t)(gout + opos) & 3u);
         uint8_t *const base = gout + opos - mis;  // byte x of the chunk lives at base[x]; base is dword aligned
-        C.heads[lane] = 0;
-        C.haz[lane] = 0;
+        if (lane < CHUNK_BYTES / 32) {
+            C.heads[lane] = 0;
+            C.haz[lane] = 0;
+        }
         WSYNC();
         uint32_t run = mis, nc = 0;
         bool too_far = false;
@@ -564,16 +558,16 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
         const uint32_t xend = run;  // offsets [mis, xend) are produced by this chunk
         WSYNC();
         {
-            const uint32_t hw = C.heads[lane];
+            const uint32_t hw = lane < CHUNK_BYTES / 32 ? C.heads[lane] : 0u;
             const uint32_t pc = (uint32_t)__popc(hw);
-            C.wpre[lane] = wave_incl_scan(pc) - pc;
+            const uint32_t ex = wave_incl_scan(pc) - pc;
+            if (lane < CHUNK_BYTES / 32) C.wpre[lane] = ex;
         }
         WSYNC();
         STAT_ACC(16);
         // ---- steps
         uint32_t lo = mis;  // everything below is already in memory
-        bool pend_any = false;  // a step whose bytes are assembled but not stored yet
-        uint32_t pend_x0 = 0, pend_word = 0, pend_mask = 0, pend_lo = 0x7fffffffu;
+        uint8_t *const outb = (uint8_t *)C.out;
         while (lo < xend) {
             STAT_ADD(14, 1);
             const uint32_t x0 = (lo & ~3u) + 4u * lane;
@@ -612,7 +606,6 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             }
             uint32_t byte[4], srcx[4];
             bool want[4], isld[4];
-            const uint32_t xcap = cap - (opos - mis);  // offsets at or above lie behind the output capacity
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t x = x0 + j;
@@ -620,43 +613,55 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
                 const uint32_t off = x - st[j];
                 const uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)val));  // off / val for off, val < 512
                 srcx[j] = st[j] - val + (val >= len ? off : off - q * val);
-                want[j] = (x >= lo) & (x < e) & (x < xcap);
+                want[j] = (x >= lo) & (x < e);
                 isld[j] = want[j] & (len != 0);
                 byte[j] = val & 0xffu;
             }
             // all four loads go out before any is waited for
-            // Software pipeline: this step's loads are issued before the previous step's store, so waiting for the
-            // loads does not wait for that store (memory operations retire in issue order) -- unless this step reads
-            // what the previous one wrote.
-            uint32_t dep = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) dep |= (isld[j] && (int32_t)srcx[j] >= (int32_t)pend_lo) ? 1u : 0u;
-            if (pend_any && __any(dep != 0)) {
-                emit_step(base, pend_x0, pend_word, pend_mask);
-                pend_any = false;
-                pend_mask = 0;
-            }
+            // sources inside the chunk come from its LDS image, the others from the output in HBM
             uint8_t ld[4] = {0, 0, 0, 0};
 #ifndef CHIP_EXP_NOLOAD
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (isld[j]) ld[j] = base[(int32_t)srcx[j]];
+                if (isld[j] && (int32_t)srcx[j] < (int32_t)mis) ld[j] = base[(int32_t)srcx[j]];
 #endif
-            if (pend_any) emit_step(base, pend_x0, pend_word, pend_mask);
-            pend_word = 0;
-            pend_mask = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (isld[j] && (int32_t)srcx[j] >= (int32_t)mis) ld[j] = outb[srcx[j]];
+            uint32_t word = 0, mask = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 byte[j] = isld[j] ? (uint32_t)ld[j] : byte[j];
-                pend_word |= byte[j] << (8 * j);
-                pend_mask |= want[j] ? 1u << j : 0u;
+                word |= byte[j] << (8 * j);
+                mask |= want[j] ? 1u << j : 0u;
             }
-            pend_x0 = x0;
-            pend_lo = lo;
-            pend_any = true;
+            if (mask == 15u) {
+                C.out[x0 >> 2] = word;
+            } else if (mask) {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if ((mask >> j) & 1u) outb[x0 + j] = (uint8_t)(word >> (8 * j));
+            }
+            WSYNC();  // the next step may read these bytes
             lo = e;
         }
-        if (pend_any) emit_step(base, pend_x0, pend_word, pend_mask);
+        // ---- the finished chunk: offsets [mis, min(xend, xcap)) of the LDS image go to HBM
+        {
+            const uint32_t xcap = cap - (opos - mis);
+            const uint32_t xe = xend < xcap ? xend : xcap;
+#ifndef CHIP_EXP_NOSTORE
+            for (uint32_t xq = 4u * lane; xq < xe; xq += 256u) {
+                const uint32_t wv = C.out[xq >> 2];
+                if (xq >= mis && xq + 4u <= xe) {
+                    *(uint32_t *)(base + xq) = wv;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if (xq + j >= mis && xq + j < xe) base[xq + j] = (uint8_t)(wv >> (8 * j));
+                }
+            }
+#endif
+        }
         STAT_ACC(17);
         opos += xend - mis;
         c0 += nc;
