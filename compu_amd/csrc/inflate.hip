@@ -574,17 +574,14 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             const uint32_t wi = x0 >> 5, sh = x0 & 31u;
             const bool inmap = wi < CHUNK_BYTES / 32;
             const uint32_t hw = inmap ? C.heads[wi] : 0u, wp = inmap ? C.wpre[wi] : 0u, hz = inmap ? (C.haz[wi] >> sh) & 15u : 0u;
-            uint32_t r[4], tk[4], st[4];
+            uint32_t r[4], tk[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t n = wp + (uint32_t)__popc(hw & ((2u << (sh + j)) - 1u));  // token starts at or below x0 + j
                 r[j] = n ? (n <= CHUNK_TOKENS ? n - 1u : CHUNK_TOKENS - 1u) : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                tk[j] = C.tok[r[j]];
-                st[j] = C.start[r[j]];
-            }
+            for (int j = 0; j < 4; j++) tk[j] = C.tok[r[j]];
             // the step ends 256 bytes behind its dword-aligned start, at the chunk end, or at the first match
             // that starts behind lo and reads bytes at or above lo
             uint32_t e = (lo & ~3u) + 256u;
@@ -594,9 +591,10 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
 #pragma unroll
                 for (int j = 3; j >= 0; j--) {
                     const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
-                    const uint32_t srcend = st[j] - val + (len < val ? len : val);
-                    const bool conf = ((hz >> j) & 1u) && st[j] > lo && (int32_t)srcend > (int32_t)lo;
-                    first_conf = conf ? x0 + j : first_conf;
+                    const uint32_t st = x0 + j;  // a hazard bit sits on the first byte of its match
+                    const uint32_t srcend = st - val + (len < val ? len : val);
+                    const bool conf = ((hz >> j) & 1u) && st > lo && (int32_t)srcend > (int32_t)lo;
+                    first_conf = conf ? st : first_conf;
                 }
                 const uint64_t cm = __ballot(first_conf != 0xffffffffu);
                 if (cm) {
@@ -606,16 +604,27 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             }
             uint32_t byte[4], srcx[4];
             bool want[4], isld[4];
+            bool overlap = false;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const uint32_t x = x0 + j;
                 const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
-                const uint32_t off = x - st[j];
-                const uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)val));  // off / val for off, val < 512
-                srcx[j] = st[j] - val + (val >= len ? off : off - q * val);
+                srcx[j] = x - val;  // right unless the match overlaps itself (distance < length)
                 want[j] = (x >= lo) & (x < e);
                 isld[j] = want[j] & (len != 0);
+                overlap = overlap | (isld[j] & (val < len));
                 byte[j] = val & 0xffu;
+            }
+            if (__any(overlap)) {
+                // a self-overlapping match repeats its first `distance` bytes: source = start - distance + (offset mod distance)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
+                    const uint32_t st = C.start[r[j]];
+                    const uint32_t off = x0 + j - st;
+                    const uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)val));  // off / val for off, val < 512
+                    if (val < len) srcx[j] = st - val + (off - q * val);
+                }
             }
             // all four loads go out before any is waited for
             // sources inside the chunk come from its LDS image, the others from the output in HBM
