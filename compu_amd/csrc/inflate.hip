@@ -1012,18 +1012,20 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             // the whole section (<= 316 symbols of <= 14 bits) is staged once and read through a 64-bit
             // register window, so the only latency per symbol is the code-length table lookup
             win_ensure(L, w, pos, 316 * 14 + 64);
+            // everything in this loop is wave-uniform: the LDS reads are made scalar (readfirstlane) so that the
+            // loop runs on the scalar unit and leaves the vector issue slots to the other waves
             uint32_t nxt = (pos >> 5) - w.win0;
-            uint64_t bb = (((uint64_t)L.inbuf[nxt + 1] << 32) | L.inbuf[nxt]) >> (pos & 31u);
+            uint64_t bb = (((uint64_t)rdfirst(L.inbuf[nxt + 1]) << 32) | rdfirst(L.inbuf[nxt])) >> (pos & 31u);
             uint32_t cnt = 64u - (pos & 31u);
             nxt += 2;
             while (have < total) {
                 if (cnt < 32) {
-                    bb |= (uint64_t)L.inbuf[nxt++] << cnt;
+                    bb |= (uint64_t)rdfirst(L.inbuf[nxt++]) << cnt;
                     cnt += 32;
                 }
                 const uint32_t lo32 = (uint32_t)bb;
-                uint32_t e = L.hdr.cl_lut[lo32 & 127u];
-                uint32_t cl = e & 15u, sym = e >> 16;
+                const uint32_t e = rdfirst(L.hdr.cl_lut[lo32 & 127u]);
+                const uint32_t cl = e & 15u, sym = e >> 16;
                 if (sym < 16) {
                     if (pos + cl > end_bit) {
                         status = CHIP_NEED_INPUT;
@@ -1037,12 +1039,12 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
                     cnt -= cl;
                     continue;
                 }
-                uint32_t eb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+                const uint32_t eb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
                 if (pos + cl + eb > end_bit) {
                     status = CHIP_NEED_INPUT;
                     break;
                 }
-                uint32_t rep = (sym == 18 ? 11u : 3u) + bfe(lo32, cl, eb);
+                const uint32_t rep = (sym == 18 ? 11u : 3u) + ((lo32 >> cl) & ((1u << eb) - 1u));
                 uint32_t val = 0;
                 if (sym == 16) {
                     if (have == 0) {
@@ -1065,6 +1067,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             }
             if (status != ST_RUNNING) break;
             WSYNC();
+            STAT_ACC(4);
             if (L.hdr.lens[256] == 0) {
                 status = Z_DATA_ERROR;
                 break;
@@ -1074,7 +1077,9 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
                 status = Z_DATA_ERROR;
                 break;
             }
+            STAT_ACC(5);
             finish_tables(L);
+            STAT_ACC(7);
         }
         STAT_ACC(0);
         decode_block(L, w, pos, end_bit, gout, opos, cap, status, grow STAT_ARG);
