@@ -447,9 +447,13 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 // popcount), a literal's byte comes from the token, a match byte is loaded from the output written
 // earlier -- from the chunk's own output, which is assembled in LDS, or from HBM when the source lies
 // below the chunk -- and the finished chunk goes out with coalesced dword stores.
-constexpr uint32_t CHUNK_GROUPS = 4;
+#ifndef CHIP_CHUNK_GROUPS
+#define CHIP_CHUNK_GROUPS 4
+#define CHIP_CHUNK_BYTES 1024
+#endif
+constexpr uint32_t CHUNK_GROUPS = CHIP_CHUNK_GROUPS;
 constexpr uint32_t CHUNK_TOKENS = 64 * CHUNK_GROUPS;
-constexpr uint32_t CHUNK_BYTES = 1024;
+constexpr uint32_t CHUNK_BYTES = CHIP_CHUNK_BYTES;
 constexpr uint32_t CHUNK_LDS_WORDS = CHUNK_TOKENS + CHUNK_TOKENS / 2 + 3 * (CHUNK_BYTES / 32) + 2 + CHUNK_BYTES / 4 + 2;
 static_assert(CHUNK_LDS_WORDS <= IN_DW + ROW_WORDS * 64, "the chunk state lives in the input window and the boundary rows");
 static_assert(CHUNK_BYTES / 32 <= 64, "one wave scan covers the bitmap words");
