@@ -1011,63 +1011,54 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
                 status = Z_DATA_ERROR;
                 break;
             }
-            // code lengths of the two alphabets (sequential: each symbol's position depends on the previous)
-            uint32_t have = 0, total = nlen + ndist, prev = 0;
-            // the whole section (<= 316 symbols of <= 14 bits) is staged once and read through a 64-bit
-            // register window, so the only latency per symbol is the code-length table lookup
-            win_ensure(L, w, pos, 316 * 14 + 64);
-            // everything in this loop is wave-uniform: the LDS reads are made scalar (readfirstlane) so that the
-            // loop runs on the scalar unit and leaves the vector issue slots to the other waves
-            uint32_t nxt = (pos >> 5) - w.win0;
-            uint64_t bb = (((uint64_t)rdfirst(L.inbuf[nxt + 1]) << 32) | rdfirst(L.inbuf[nxt])) >> (pos & 31u);
-            uint32_t cnt = 64u - (pos & 31u);
-            nxt += 2;
+            // Code lengths of the two alphabets, 64 bit positions per round: lane i decodes the code-length symbol
+            // that would start at bit pos + i; the symbols really present are the chain 0 -> 0 + bits(0) -> ...,
+            // followed with scalar readlanes; a prefix sum of the run lengths along the chain gives every symbol
+            // its place in lens[], and a running maximum hands each "repeat previous" symbol the last explicit
+            // length in front of it.  (zlib reads these one by one; errors keep its order: the first bad symbol.)
+            uint32_t have = 0, total = nlen + ndist, prevlen = 0;
+            win_ensure(L, w, pos, 316 * 14 + 160);
+            for (uint32_t k = lane; k < 320; k += 64) L.hdr.lens[k] = 0;  // zero runs (17/18) then need no stores
+            WSYNC();
             while (have < total) {
-                if (cnt < 32) {
-                    bb |= (uint64_t)rdfirst(L.inbuf[nxt++]) << cnt;
-                    cnt += 32;
-                }
-                const uint32_t lo32 = (uint32_t)bb;
-                const uint32_t e = rdfirst(L.hdr.cl_lut[lo32 & 127u]);
+                const uint32_t bp = pos + lane;
+                uint32_t lo, hi;
+                win_bits(L, w, bp, lo, hi);
+                const uint32_t e = L.hdr.cl_lut[lo & 127u];
                 const uint32_t cl = e & 15u, sym = e >> 16;
-                if (sym < 16) {
-                    if (pos + cl > end_bit) {
-                        status = CHIP_NEED_INPUT;
-                        break;
-                    }
-                    if (lane == 0) L.hdr.lens[have] = (uint8_t)sym;
-                    prev = sym;
-                    have++;
-                    pos += cl;
-                    bb >>= cl;
-                    cnt -= cl;
-                    continue;
-                }
-                const uint32_t eb = sym == 16 ? 2u : sym == 17 ? 3u : 7u;
-                if (pos + cl + eb > end_bit) {
-                    status = CHIP_NEED_INPUT;
+                const uint32_t eb = sym < 16 ? 0u : sym == 16 ? 2u : sym == 17 ? 3u : 7u;
+                const uint32_t tl = cl + eb;
+                const uint32_t run = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + bfe(lo, cl, eb);
+                const uint32_t nx = lane + tl;
+                uint64_t onm = 0;
+                for (uint32_t cur = 0; cur < 64u; cur = rdlane(nx, cur)) onm |= 1ull << cur;
+                const bool on = (onm >> lane) & 1ull;
+                const uint32_t c = on ? run : 0u;
+                const uint32_t incl = wave_incl_scan(c);
+                const uint32_t start = have + incl - c;
+                const bool need = on && start < total;
+                uint32_t bad = 0;  // zlib's checks, in its order, for the symbol this lane holds
+                if (need && bp + tl > end_bit) bad = 1;
+                else if (need && sym == 16 && start == 0) bad = 2;
+                else if (need && sym >= 16 && start + run > total) bad = 2;
+                const uint64_t badm = __ballot(bad != 0);
+                const uint32_t fb = badm ? (uint32_t)__ffsll((long long)badm) - 1u : 64u;
+                const bool ok = need && lane < fb;
+                const uint32_t expl = sym < 16 ? sym : 0u;  // the length this symbol leaves as "previous"
+                const uint32_t m = wave_incl_max_scan((ok && sym != 16) ? (((lane + 1u) << 8) | expl) : 0u);
+                const uint32_t v = sym == 16 ? (m ? m & 0xffu : prevlen) : expl;
+                if (ok && sym < 16) L.hdr.lens[start] = (uint8_t)sym;
+                if (ok && sym == 16)
+                    for (uint32_t j = 0; j < run; j++) L.hdr.lens[start + j] = (uint8_t)v;
+                if (badm) {
+                    status = rdlane(bad, fb) == 1 ? (int32_t)CHIP_NEED_INPUT : Z_DATA_ERROR;
                     break;
                 }
-                const uint32_t rep = (sym == 18 ? 11u : 3u) + ((lo32 >> cl) & ((1u << eb) - 1u));
-                uint32_t val = 0;
-                if (sym == 16) {
-                    if (have == 0) {
-                        status = Z_DATA_ERROR;
-                        break;
-                    }
-                    val = prev;
-                } else {
-                    prev = 0;
-                }
-                if (have + rep > total) {
-                    status = Z_DATA_ERROR;
-                    break;
-                }
-                for (uint32_t j = lane; j < rep; j += 64) L.hdr.lens[have + j] = (uint8_t)val;
-                have += rep;
-                pos += cl + eb;
-                bb >>= cl + eb;
-                cnt -= cl + eb;
+                const uint64_t okm = __ballot(ok);
+                const uint32_t lv = 63u - (uint32_t)__clzll((long long)okm);  // lane 0 is always ok here
+                have = rdlane(start + run, lv);
+                pos += lv + rdlane(tl, lv);
+                prevlen = rdlane(v, lv);
             }
             if (status != ST_RUNNING) break;
             WSYNC();
