@@ -463,7 +463,7 @@ struct ChunkLds {
     uint16_t *start;   // [CHUNK_TOKENS] output offset of the token, relative to the chunk's dword-aligned base
     uint32_t *heads;   // [CHUNK_BYTES / 32] bit x set = a token starts at offset x
     uint32_t *wpre;    // [CHUNK_BYTES / 32] token starts in all lower words
-    uint32_t *haz;     // [CHUNK_BYTES / 32] bit x set = the match starting at x reads bytes less than 260 below x
+    uint32_t *dmap;    // [CHUNK_BYTES / 32] bit x set = byte x waits for a source byte of its own step (all clear between steps)
     uint32_t *pmask;   // [2] gather scratch: piece starts inside a 64-token group
     uint32_t *out;     // [CHUNK_BYTES / 4 + 2] the chunk's output bytes by offset
 };
@@ -476,8 +476,8 @@ __device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
     c.start = (uint16_t *)(c.tok + CHUNK_TOKENS);
     c.heads = c.tok + CHUNK_TOKENS + CHUNK_TOKENS / 2;
     c.wpre = c.heads + CHUNK_BYTES / 32;
-    c.haz = c.wpre + CHUNK_BYTES / 32;
-    c.pmask = c.haz + CHUNK_BYTES / 32;
+    c.dmap = c.wpre + CHUNK_BYTES / 32;
+    c.pmask = c.dmap + CHUNK_BYTES / 32;
     c.out = c.pmask + 2;
     return c;
 }
@@ -522,7 +522,7 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
         uint8_t *const base = gout + opos - mis;  // byte x of the chunk lives at base[x]; base is dword aligned
         if (lane < CHUNK_BYTES / 32) {
             C.heads[lane] = 0;
-            C.haz[lane] = 0;
+            C.dmap[lane] = 0;
         }
         WSYNC();
         uint32_t run = mis, nc = 0;
@@ -546,9 +546,6 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
                 C.tok[64u * j + lane] = t;
                 C.start[64u * j + lane] = (uint16_t)start;
                 atomicOr(&C.heads[start >> 5], 1u << (start & 31u));
-                // a step is at most 259 bytes: only a match whose source ends less than that below its start can
-                // ever read what its own step has yet to write
-                if (len && val < 260u + (len < val ? len : val)) atomicOr(&C.haz[start >> 5], 1u << (start & 31u));
             }
             nc += nacc;
             if (stopm) {
@@ -577,7 +574,7 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             const uint32_t x0 = (lo & ~3u) + 4u * lane;
             const uint32_t wi = x0 >> 5, sh = x0 & 31u;
             const bool inmap = wi < CHUNK_BYTES / 32;
-            const uint32_t hw = inmap ? C.heads[wi] : 0u, wp = inmap ? C.wpre[wi] : 0u, hz = inmap ? (C.haz[wi] >> sh) & 15u : 0u;
+            const uint32_t hw = inmap ? C.heads[wi] : 0u, wp = inmap ? C.wpre[wi] : 0u;
             uint32_t r[4], tk[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -586,26 +583,9 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) tk[j] = C.tok[r[j]];
-            // the step ends 256 bytes behind its dword-aligned start, at the chunk end, or at the first match
-            // that starts behind lo and reads bytes at or above lo
+            // the step ends 256 bytes behind its dword-aligned start or at the chunk end
             uint32_t e = (lo & ~3u) + 256u;
             e = e < xend ? e : xend;
-            if (__any(hz != 0)) {
-                uint32_t first_conf = 0xffffffffu;
-#pragma unroll
-                for (int j = 3; j >= 0; j--) {
-                    const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
-                    const uint32_t st = x0 + j;  // a hazard bit sits on the first byte of its match
-                    const uint32_t srcend = st - val + (len < val ? len : val);
-                    const bool conf = ((hz >> j) & 1u) && st > lo && (int32_t)srcend > (int32_t)lo;
-                    first_conf = conf ? st : first_conf;
-                }
-                const uint64_t cm = __ballot(first_conf != 0xffffffffu);
-                if (cm) {
-                    const uint32_t fc = rdlane(first_conf, (uint32_t)__ffsll((long long)cm) - 1u);
-                    e = fc < e ? fc : e;
-                }
-            }
             uint32_t byte[4], srcx[4];
             bool want[4], isld[4];
             bool overlap = false;
@@ -630,17 +610,21 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
                     if (val < len) srcx[j] = st - val + (off - q * val);
                 }
             }
-            // all four loads go out before any is waited for
-            // sources inside the chunk come from its LDS image, the others from the output in HBM
+            // sources below the chunk come from the output in HBM, sources below this step from the chunk's LDS image;
+            // a byte whose source lies inside this very step waits (rare: short distances)
             uint8_t ld[4] = {0, 0, 0, 0};
+            uint32_t dm = 0;  // this lane's waiting bytes
 #ifndef CHIP_EXP_NOLOAD
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (isld[j] && (int32_t)srcx[j] < (int32_t)mis) ld[j] = base[(int32_t)srcx[j]];
 #endif
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (isld[j] && (int32_t)srcx[j] >= (int32_t)mis) ld[j] = outb[srcx[j]];
+            for (int j = 0; j < 4; j++) {
+                const bool inchunk = isld[j] && (int32_t)srcx[j] >= (int32_t)mis;
+                if (inchunk && srcx[j] < lo) ld[j] = outb[srcx[j]];
+                dm |= (inchunk && srcx[j] >= lo) ? 1u << j : 0u;
+            }
             uint32_t word = 0, mask = 0;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
@@ -648,6 +632,7 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
                 word |= byte[j] << (8 * j);
                 mask |= want[j] ? 1u << j : 0u;
             }
+            mask &= ~dm;
             if (mask == 15u) {
                 C.out[x0 >> 2] = word;
             } else if (mask) {
@@ -655,7 +640,35 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
                 for (int j = 0; j < 4; j++)
                     if ((mask >> j) & 1u) outb[x0 + j] = (uint8_t)(word >> (8 * j));
             }
-            WSYNC();  // the next step may read these bytes
+            if (__any(dm != 0)) {
+                // waiting bytes are flagged in dmap; each round copies those whose source is not itself waiting
+                // (the lowest waiting byte never is, so every round makes progress)
+                if (dm) atomicOr(&C.dmap[wi], dm << sh);
+                WSYNC();
+                while (__any(dm != 0)) {
+                    uint32_t got = 0;
+                    uint8_t b[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        if ((dm >> j) & 1u) {
+                            const uint32_t sx = srcx[j];
+                            if (!((C.dmap[sx >> 5] >> (sx & 31u)) & 1u)) {
+                                b[j] = outb[sx];
+                                got |= 1u << j;
+                            }
+                        }
+                    }
+                    WSYNC();  // every test of this round comes before any flag is cleared
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+                        if ((got >> j) & 1u) outb[x0 + j] = b[j];
+                    if (got) atomicAnd(&C.dmap[wi], ~(got << sh));
+                    dm &= ~got;
+                    WSYNC();
+                }
+            } else {
+                WSYNC();  // the next step may read these bytes
+            }
             lo = e;
         }
         // ---- the finished chunk: offsets [mis, min(xend, xcap)) of the LDS image go to HBM
