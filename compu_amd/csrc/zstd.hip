@@ -106,21 +106,23 @@ __device__ __forceinline__ bool bb_init(const Bits &b, BackBits &s, uint32_t byt
     return true;
 }
 
-// The sequence bitstream is read backward through a 1 KiB LDS window and a 64-bit register buffer
-// (next bit at bit 63): one LDS read per 32 consumed bits instead of two per field.
+// The sequence bitstream is read backward through a 1 KiB LDS window.  Once per sequence the 64 bits
+// just below the read position are formed from three window dwords; the fields of the sequence are
+// then cut from the top of that register pair, with one reload in the rare case a sequence needs more
+// than 64 bits.  Bits below the stream start are whatever precedes it in the input: a read that
+// reaches them drives `avail` negative, which the caller treats as corruption whatever the bits were.
 struct SeqBits {
     uint32_t lo;    // absolute bit index of the stream start
-    int32_t avail;  // unread bits of the stream (negative once over-read)
+    int32_t avail;  // unread bits of the stream (negative once over-read), not counting `used`
     int32_t win0;   // absolute dword index held in seqwin[0]
-    uint64_t buf;   // unread bits, left aligned
-    int32_t cnt;    // valid bits in buf
-    int32_t ptr;    // absolute bit index of the lowest bit already in buf
+    uint64_t w;     // the 64 bits below lo + avail (bit 63 = the next bit)
+    uint32_t used;  // bits already cut from w
 };
 
 __device__ __forceinline__ void sq_fill(ZLds &L, const Bits &b, SeqBits &s)
 {
     WSYNC();
-    s.win0 = (s.ptr >> 5) + 2 - 256;
+    s.win0 = ((int32_t)(s.lo + (uint32_t)s.avail) >> 5) + 2 - 256;
     for (int32_t k = (int32_t)lane_id(); k < 256; k += 64) {
         int32_t i = s.win0 + k;
         L.seqwin[k] = (i >= 0 && (uint32_t)i < b.total_dw) ? b.g32[i] : 0u;
@@ -128,54 +130,35 @@ __device__ __forceinline__ void sq_fill(ZLds &L, const Bits &b, SeqBits &s)
     WSYNC();
 }
 
-// make sure the dwords the next `need` bits (<= 160) come from are staged
-__device__ __forceinline__ void sq_ensure(ZLds &L, const Bits &b, SeqBits &s, int32_t need)
+// commit the bits cut so far and form the next 64; restages the window when the read position (plus the
+// <= 96 bits a sequence can take) comes near its lower end
+__device__ __forceinline__ void sq_load(ZLds &L, const Bits &b, SeqBits &s)
 {
-    int32_t lowbit = s.ptr - need;
-    if (lowbit < (int32_t)s.lo) lowbit = (int32_t)s.lo;
-    if ((lowbit >> 5) < s.win0) sq_fill(L, b, s);
-}
-
-// Pull the next lower dword of the stream into the register buffer when 32 bits or fewer are left --
-// branch-free.  Bits below the stream start are whatever precedes it in the input: a read that reaches
-// them drives `avail` negative, which the caller treats as corruption whatever the bits were.
-__device__ __forceinline__ void sq_refill(const ZLds &L, SeqBits &s)
-{
-    const bool need = s.cnt <= 32;
-    int32_t i = ((s.ptr - 32) >> 5) - s.win0;
+    s.avail -= (int32_t)s.used;
+    s.used = 0;
+    const int32_t q = (int32_t)s.lo + s.avail - 64;  // lowest bit of the 64 (may lie below the stream: see above)
+    if (((q - 96) >> 5) < s.win0) sq_fill(L, b, s);
+    int32_t i = (q >> 5) - s.win0;
     i = i < 0 ? 0 : i;
-    const uint32_t dw = L.seqwin[i];
-    s.buf |= need ? (uint64_t)dw << (32 - s.cnt) : 0ull;
-    s.cnt += need ? 32 : 0;
-    s.ptr -= need ? 32 : 0;
+    const uint32_t d0 = L.seqwin[i], d1 = L.seqwin[i + 1], d2 = L.seqwin[i + 2];
+    const uint32_t sh = (uint32_t)q & 31u;
+    s.w = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
 }
 
 __device__ __forceinline__ void sq_init(ZLds &L, const Bits &b, SeqBits &s, uint32_t lo, int32_t avail)
 {
     s.lo = lo;
     s.avail = avail;
-    const uint32_t top = lo + (uint32_t)avail;
-    s.ptr = (int32_t)top;
-    s.buf = 0;
-    s.cnt = 0;
-    sq_fill(L, b, s);
-    if (top & 31u) {  // partial top dword
-        const uint32_t k = top & 31u;
-        uint32_t dw = L.seqwin[(int32_t)(top >> 5) - s.win0] & ((1u << k) - 1u);
-        s.ptr = (int32_t)(top & ~31u);
-        if (s.ptr < (int32_t)lo) dw &= ~((1u << ((int32_t)lo - s.ptr)) - 1u);
-        s.buf = (uint64_t)dw << (64 - k);
-        s.cnt = (int32_t)k;
-    }
+    s.used = 0;
+    s.win0 = 0x7fffff00;  // forces the first staging
+    sq_load(L, b, s);
 }
 
-__device__ __forceinline__ uint32_t sq_read(const ZLds &L, SeqBits &s, uint32_t n)  // n <= 32
+__device__ __forceinline__ uint32_t sq_read(ZLds &L, const Bits &b, SeqBits &s, uint32_t n)  // n <= 32
 {
-    sq_refill(L, s);
-    const uint32_t v = n ? (uint32_t)(s.buf >> (64 - n)) : 0u;
-    s.buf = n ? s.buf << n : s.buf;
-    s.cnt -= (int32_t)n;
-    s.avail -= (int32_t)n;
+    if (s.used + n > 64u) sq_load(L, b, s);
+    const uint32_t v = n ? (uint32_t)((s.w << (s.used & 63u)) >> ((64u - n) & 63u)) : 0u;
+    s.used += n;
     return v;
 }
 
@@ -801,7 +784,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 if (!bb_init(b, s0, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
                 SeqBits s;
                 sq_init(L, b, s, s0.lo, s0.avail);
-                uint32_t sl = sq_read(L, s, L.ll.al), so = sq_read(L, s, L.of.al), sm = sq_read(L, s, L.ml.al);
+                uint32_t sl = sq_read(L, b, s, L.ll.al), so = sq_read(L, b, s, L.of.al), sm = sq_read(L, b, s, L.ml.al);
+                s.avail -= (int32_t)s.used;
+                s.used = 0;
                 if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
                 const uint8_t *litsrc = lit_mode == 0 ? (const uint8_t *)b.g32 + lit_in : gout + lit_out;
                 // sequences are decoded 64 at a time (the FSE state chain is serial; lane j keeps sequence j)
@@ -812,7 +797,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t ll = 0, ml = 0, off = 0;
                     uint32_t dec_bad = 64;  // first sequence of the chunk whose decode is corrupt (verdicts keep stream order)
                     for (uint32_t j = 0; j < cn; j++) {
-                        sq_ensure(L, b, s, 160);
+                        sq_load(L, b, s);
                         const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
                         const uint32_t oc = eo & 0xffu, mc = em & 0xffu, lc = el & 0xffu;
                         if (oc > 31) {
@@ -821,7 +806,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         }
                         // three reads per sequence: the offset's extra bits, then the match- and literal-length
                         // extras together (<= 32 bits), and further down the three state updates together
-                        const uint32_t obits = sq_read(L, s, oc);
+                        const uint32_t obits = sq_read(L, b, s, oc);
                         const uint64_t ov = (1ull << oc) + obits;
                         if (mc > 52 || lc > 35) {
                             dec_bad = j;
@@ -829,7 +814,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         }
                         const uint32_t mt = L.mltab[mc], lt = L.lltab[lc];
                         const uint32_t mb = mt >> 24, lb = lt >> 24;
-                        const uint32_t mlx = sq_read(L, s, mb + lb);
+                        const uint32_t mlx = sq_read(L, b, s, mb + lb);
                         const uint32_t mlen = (mt & 0xffffffu) + (lb >= 32 ? 0u : (mlx >> lb));
                         const uint32_t llen = (lt & 0xffffffu) + (mlx & ((1u << lb) - 1u));
                         uint64_t offset;
@@ -852,12 +837,12 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         }
                         if (i0 + j + 1 < nseq) {
                             const uint32_t nl = (el >> 8) & 0xffu, nm = (em >> 8) & 0xffu, no = (eo >> 8) & 0xffu;
-                            const uint32_t st3 = sq_read(L, s, nl + nm + no);  // <= 9 + 9 + 8 bits: LL, then ML, then OF
+                            const uint32_t st3 = sq_read(L, b, s, nl + nm + no);  // <= 9 + 9 + 8 bits: LL, then ML, then OF
                             sl = (el >> 16) + (st3 >> (nm + no));
                             sm = (em >> 16) + ((st3 >> no) & ((1u << nm) - 1u));
                             so = (eo >> 16) + (st3 & ((1u << no) - 1u));
                         }
-                        if (s.avail < 0) {
+                        if (s.avail < (int32_t)s.used) {
                             dec_bad = j;
                             break;
                         }
@@ -1000,7 +985,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     opos += OB;
                     lpos += LB;
                 }
-                if (s.avail != 0) ZFAIL(ZSTD_E_CORRUPTION);  // the bitstream must be consumed exactly
+                if (s.avail != (int32_t)s.used) ZFAIL(ZSTD_E_CORRUPTION);  // the bitstream must be consumed exactly
             }
             const uint32_t restl = regen - lpos;
             if ((uint64_t)opos + restl > out_limit) ZFAIL(70);
