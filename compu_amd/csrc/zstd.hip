@@ -164,6 +164,208 @@ __device__ __forceinline__ uint32_t sq_read(ZLds &L, const Bits &b, SeqBits &s, 
 
 __device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { return rd32_at(b, byte * 8u) & 0xffu; }
 
+// ---- four-stream Huffman literals, 16 lanes per stream -------------------------------------------------
+// Same idea as the inflate walk (inflate.hip): per super-round lane k of a stream starts HS_BITS * k bits below
+// the stream's current read position (a guess, except for k = 0), decodes symbol boundaries from there, marks the
+// boundaries inside its own segment in an LDS bitmap and, once below its segment, looks every new position up in
+// the bitmap of the lane that owns the segment it is in; at the first hit the two chains are the same from there
+// on.  The true chain is lane 0's up to its join, then the joined lane's from the join on, and so on; a popcount
+// gives the index of the joined symbol and a prefix sum every piece's place in the literal buffer.  A second
+// pass then decodes exactly the owned symbols again and stores them.  Huffman codes re-synchronise within a few
+// symbols, so the 16 lanes cover ~16 x 224 bits per round with ~50 + 40 serial steps instead of ~570.
+constexpr int HS_BITS = 224;
+constexpr int HXT_BITS = 512;
+constexpr int HROW_WORDS = HS_BITS / 32;
+static_assert(HROW_WORDS * 64 <= 256 + 64 + 192, "boundary rows live in seqwin + xheads + xpar");
+
+struct HufStream {      // per lane: the stream its group of 16 lanes decodes
+    uint32_t lo;        // absolute bit index of the stream's first bit
+    uint32_t top;       // absolute bit index just above the next unread bit
+    uint32_t want;      // symbols the stream must hold
+    uint32_t done;      // symbols stored so far
+    uint32_t out;       // index in gout of the stream's first literal
+};
+
+struct HufBits {  // backward reader over absolute bit positions, next bit at bit 63 of buf
+    int32_t ptr, cnt;
+    uint64_t buf;
+    uint32_t nextdw;
+};
+
+__device__ __forceinline__ uint32_t huf_load_dw(const Bits &b, int32_t lo, int32_t bit)
+{
+    const int32_t i = bit >> 5;
+    if (bit + 32 <= lo || i < 0 || (uint32_t)i >= b.total_dw) return 0u;
+    uint32_t dw = b.g32[i];
+    if (bit < lo) dw &= ~((1u << (lo - bit)) - 1u);
+    return dw;
+}
+
+__device__ __forceinline__ void huf_bits_init(const Bits &b, HufBits &h, int32_t lo, uint32_t pos)
+{
+    h.ptr = (int32_t)(pos & ~31u);
+    h.cnt = (int32_t)(pos & 31u);
+    h.buf = h.cnt ? (uint64_t)(huf_load_dw(b, lo, h.ptr) & ((1u << h.cnt) - 1u)) << (64 - h.cnt) : 0ull;
+    h.nextdw = huf_load_dw(b, lo, h.ptr - 32);
+}
+
+__device__ __forceinline__ uint32_t huf_bits_peek(const Bits &b, HufBits &h, int32_t lo, uint32_t hbits)
+{
+    if (h.cnt <= 32) {
+        h.ptr -= 32;
+        h.buf |= (uint64_t)h.nextdw << (32 - h.cnt);
+        h.cnt += 32;
+        h.nextdw = huf_load_dw(b, lo, h.ptr - 32);
+    }
+    return (uint32_t)(h.buf >> (64 - hbits));
+}
+
+__device__ __forceinline__ void huf_bits_skip(HufBits &h, uint32_t nb)
+{
+    h.buf <<= nb;
+    h.cnt -= (int32_t)nb;
+}
+
+// Decodes the four streams described per lane by `hs` into gout.  Returns false on a corrupt stream.
+__device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
+{
+    const uint32_t lane = lane_id(), k = lane & 15u, g0 = lane & ~15u;
+    const uint32_t hbits = L.huf_bits;
+    uint32_t *const rows = L.seqwin;                 // [word][lane]
+    uint32_t *const flags = (uint32_t *)L.weights;   // 64 words, dead once the Huffman table exists
+    uint32_t *const sidx = (uint32_t *)L.norm;       // 64 words (norm + next)
+    uint32_t *const soff = L.xpar + 128;             // 64 words behind the rows
+    enum : uint32_t { H_IDLE = 0, H_JOIN = 1, H_LIMIT = 2, H_END = 3, H_BAD = 4 };
+    bool bad = false;
+    bool live = true;  // the stream still has symbols to find
+    while (__any(live)) {
+        const uint32_t rend = hs.top - hs.lo;  // bits left in the stream
+#pragma unroll
+        for (int w = 0; w < HROW_WORDS; w++) rows[w * 64 + lane] = 0;
+        WSYNC();
+        // ---- walk
+        const uint32_t r0 = k * HS_BITS;
+        uint32_t rlim = r0 + HS_BITS + HXT_BITS;
+        rlim = rlim < 16u * HS_BITS ? rlim : 16u * HS_BITS;
+        uint32_t r = r0, nst = 0, reason = H_IDLE, jl = 64, rstop = r0;
+        bool active = live && r0 < rend;
+        if (live && k == 0 && rend == 0) reason = H_END;
+        HufBits h;
+        huf_bits_init(b, h, (int32_t)hs.lo, hs.top - (r0 < rend ? r0 : rend));
+        while (__any(active)) {
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t rr = active ? r : r0;
+                const uint32_t seg = rr / HS_BITS, off = rr - seg * HS_BITS;
+                const uint32_t bit = 1u << (off & 31u);
+                const uint32_t old = atomicOr(&rows[(off >> 5) * 64 + g0 + seg], (active && seg == k) ? bit : 0u);
+                const bool joined = active && seg != k && (old & bit);
+                const uint32_t e = L.huf[huf_bits_peek(b, h, (int32_t)hs.lo, hbits)];
+                const uint32_t nb = e >> 8;
+                uint32_t st = H_IDLE;
+                st = r + nb > rend ? (uint32_t)H_BAD : st;
+                st = joined ? (uint32_t)H_JOIN : st;
+                const bool go = active && st == H_IDLE;
+                if (active && !go) {
+                    reason = st;
+                    jl = g0 + seg;
+                    rstop = r;
+                }
+                nst += go ? 1u : 0u;
+                r += go ? nb : 0u;
+                if (go) huf_bits_skip(h, nb);
+                active = go && r < rlim && r < rend;
+                if (go && !active) {
+                    reason = r >= rend ? (uint32_t)H_END : (uint32_t)H_LIMIT;
+                    rstop = r;
+                }
+            }
+        }
+        WSYNC();
+        // ---- the true chain of every stream: lane 0 of the group, then whatever it joined, ...
+        const uint32_t nxt = reason == H_JOIN ? jl : 64u;
+        uint32_t a_join = 0;
+        if (reason == H_JOIN) {
+            const uint32_t off = rstop - (jl & 15u) * HS_BITS;
+#pragma unroll
+            for (int w = 0; w < HROW_WORDS; w++) {
+                int nbb = (int)off - 32 * w;
+                nbb = nbb < 0 ? 0 : (nbb > 32 ? 32 : nbb);
+                const uint32_t below = nbb >= 32 ? 0xffffffffu : ((1u << nbb) - 1u);
+                a_join += __popc(rows[w * 64 + jl] & below);
+            }
+        }
+        bool on = live && k == 0;
+        uint32_t jump = nxt;
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+            flags[lane] = 0;
+            WSYNC();
+            if (on && jump < 64u) flags[jump] = 1;
+            WSYNC();
+            on = on || flags[lane] != 0;
+            const uint32_t j2 = (uint32_t)__shfl((int)jump, (int)(jump & 63u), 64);
+            jump = jump < 64u ? j2 : 64u;
+            WSYNC();
+        }
+        if (on && nxt < 64u) {
+            sidx[nxt] = a_join;
+            soff[nxt] = rstop;
+        }
+        WSYNC();
+        const uint32_t a0 = k == 0 ? 0u : sidx[lane];
+        const uint32_t pstart = k == 0 ? 0u : soff[lane];  // offset below the stream top where this lane's piece starts
+        const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
+        const uint32_t incl = wave_incl_scan(cnt);
+        const uint32_t below = (uint32_t)__shfl((int)incl, (int)((g0 - 1u) & 63u), 64);  // every lane takes part: the source lane must be active
+        const uint32_t gbase = g0 ? below : 0u;
+        const uint32_t first = incl - cnt - gbase;
+        const uint32_t total = (uint32_t)__shfl((int)incl, (int)(g0 + 15u), 64) - gbase;
+        // the stream's chain ends in its highest lane that is on it
+        const uint64_t onm = __ballot(on) & (0xffffull << g0);
+        const uint32_t lz = onm ? 63u - (uint32_t)__clzll((long long)onm) : g0;
+        const uint32_t rz = (uint32_t)__shfl((int)reason, (int)lz, 64), sz = (uint32_t)__shfl((int)rstop, (int)lz, 64);
+        // ---- second pass: the owned symbols, stored
+        {
+            HufBits h2;
+            huf_bits_init(b, h2, (int32_t)hs.lo, hs.top - (on ? pstart : 0u));
+            uint8_t *dst = gout + hs.out + hs.done + first;
+            const uint32_t room = hs.want > hs.done + first ? hs.want - (hs.done + first) : 0u;  // never write past the stream's literals
+            const uint32_t n = cnt < room ? cnt : room;
+#ifndef CHIP_EXP_NOHUF
+            for (uint32_t i = 0; __any(i < n); i++) {
+                const uint32_t e = L.huf[huf_bits_peek(b, h2, (int32_t)hs.lo, hbits)];
+                if (i < n) {
+                    dst[i] = (uint8_t)e;
+                    huf_bits_skip(h2, e >> 8);
+                }
+            }
+#endif
+        }
+#ifdef CHIP_DEBUG_HUF
+        if ((lane & 15) == 0 || lane == 17) printf("l%u live%d rend%u r0%u reason%u rstop%u nst%u nxt%u a0%u on%d cnt%u first%u total%u lz%u rz%u sz%u want%u done%u\n", lane, (int)live, rend, r0, reason, rstop, nst, nxt, a0, (int)on, cnt, first, total, lz, rz, sz, hs.want, hs.done);
+#endif
+        if (live) {
+            hs.done += total;
+            hs.top -= sz;
+            if (rz == H_BAD || hs.done > hs.want) bad = true;
+            if (rz == H_END) {
+                if (hs.done != hs.want) bad = true;
+                live = false;
+            } else if (rz != H_LIMIT) {
+                live = false;  // H_BAD (or nothing found): the stream is corrupt
+                bad = true;
+            }
+            if (bad) live = false;
+        }
+        WSYNC();
+    }
+#ifdef CHIP_DEBUG_HUF
+    if ((lane & 15) == 0) printf("end l%u bad%d done%u want%u\n", lane, (int)bad, hs.done, hs.want);
+#endif
+    return !__any(bad);
+}
+
 // FSE table description (sec. 4.1.1) read forward from absolute byte `p0` (at most `n` bytes).
 // Fills L.norm; returns bytes consumed or -1.  Uniform.
 __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, int max_al, int max_sym, int &al_out, int &nsym_out)
@@ -663,9 +865,28 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     cnt_[3] = regen - 3 * seg;
                     st0 = lp + 6;
                 }
-                // lanes 0..3 each decode one stream, symbol by symbol
                 bool sbad = false;
-                if (lane < streams) {
+                if (streams == 4) {
+                    // 16 lanes per stream (see huf_decode4)
+                    const uint32_t g = lane >> 4;
+                    uint32_t myoff = st0, myout = lit_out;
+                    for (uint32_t k = 0; k < g; k++) {
+                        myoff += sz[k];
+                        myout += cnt_[k];
+                    }
+                    BackBits s;
+                    const bool okb = bb_init(b, s, myoff, sz[g]);
+                    if (__any(!okb)) ZFAIL(ZSTD_E_CORRUPTION);
+                    HufStream hs;
+                    hs.lo = s.lo;
+                    hs.top = s.lo + (uint32_t)s.avail;
+                    hs.want = cnt_[g];
+                    hs.done = 0;
+                    hs.out = myout;
+                    WSYNC();
+                    if (!huf_decode4(L, b, hs, gout)) ZFAIL(ZSTD_E_CORRUPTION);
+                    WSYNC();
+                } else if (lane < streams) {  // a single stream (small literal sections): one lane, symbol by symbol
                     uint32_t myoff = st0, myout = lit_out;
                     for (uint32_t k = 0; k < lane; k++) {
                         myoff += sz[k];
@@ -792,6 +1013,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 // sequences are decoded 64 at a time (the FSE state chain is serial; lane j keeps sequence j)
                 // and then executed together: prefix sums place every literal run and match, literal bytes
                 // and match bytes are copied 256 per step with an owner map (see inflate.hip)
+#ifdef CHIP_EXP_NOSEQ
+                nseq = 0;
+#endif
                 for (uint32_t i0 = 0; i0 < nseq; i0 += 64) {
                     const uint32_t cn = nseq - i0 < 64 ? nseq - i0 : 64;
                     uint32_t ll = 0, ml = 0, off = 0;
