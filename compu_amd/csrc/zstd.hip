@@ -999,6 +999,18 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         p += (uint32_t)c;
                         left -= (uint32_t)c;
                     } else if (!*t.valid) ZFAIL(ZSTD_E_CORRUPTION);
+                    if (mode != 3 && k != 1) {
+                        // a freshly built LL / ML table also carries, per state, how many extra bits its code reads
+                        // ([15:12] and bit 7): the serial state chain then needs no second lookup to find the next state's bits
+                        WSYNC();
+                        const uint32_t *xt = k == 0 ? L.lltab : L.mltab;
+                        const uint32_t size = 1u << *t.al;
+                        for (uint32_t u = lane; u < size; u += 64) {
+                            const uint32_t e = t.e[u];
+                            const uint32_t xb = xt[e & 63u] >> 24;
+                            t.e[u] = e | ((xb & 15u) << 12) | ((xb >> 4) << 7);
+                        }
+                    }
                 }
                 WSYNC();
                 BackBits s0;
@@ -1020,47 +1032,23 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     const uint32_t cn = nseq - i0 < 64 ? nseq - i0 : 64;
                     uint32_t ll = 0, ml = 0, off = 0;
                     uint32_t dec_bad = 64;  // first sequence of the chunk whose decode is corrupt (verdicts keep stream order)
+                    // ---- serial part: only what the next state depends on.  Per sequence: the three state entries,
+                    // the number of extra bits they imply (to find the state-update bits) and the three new states.
+                    // Lane j keeps sequence j's entries and bit position; the values are cut out in parallel below.
+                    // A chunk reads at most 64 x 89 bits, so staging the 8192-bit window once per chunk is enough.
+                    s.avail -= (int32_t)s.used;
+                    s.used = 0;
+                    if ((((int32_t)s.lo + s.avail - 64 - 64 * 96) >> 5) < s.win0) sq_fill(L, b, s);
+                    uint32_t my_el = 0, my_eo = 0, my_em = 0;
+                    int32_t my_top = 0;
                     for (uint32_t j = 0; j < cn; j++) {
                         sq_load(L, b, s);
+                        const int32_t top = (int32_t)s.lo + s.avail;
                         const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
-                        const uint32_t oc = eo & 0xffu, mc = em & 0xffu, lc = el & 0xffu;
-                        if (oc > 31) {
-                            dec_bad = j;
-                            break;
-                        }
-                        // three reads per sequence: the offset's extra bits, then the match- and literal-length
-                        // extras together (<= 32 bits), and further down the three state updates together
-                        const uint32_t obits = sq_read(L, b, s, oc);
-                        const uint64_t ov = (1ull << oc) + obits;
-                        if (mc > 52 || lc > 35) {
-                            dec_bad = j;
-                            break;
-                        }
-                        const uint32_t mt = L.mltab[mc], lt = L.lltab[lc];
-                        const uint32_t mb = mt >> 24, lb = lt >> 24;
-                        const uint32_t mlx = sq_read(L, b, s, mb + lb);
-                        const uint32_t mlen = (mt & 0xffffffu) + (lb >= 32 ? 0u : (mlx >> lb));
-                        const uint32_t llen = (lt & 0xffffffu) + (mlx & ((1u << lb) - 1u));
-                        uint64_t offset;
-                        if (ov > 3) {
-                            offset = ov - 3;
-                            rep2 = rep1;
-                            rep1 = rep0;
-                            rep0 = (uint32_t)offset;
-                        } else {
-                            const uint32_t idx = (uint32_t)ov - (llen != 0 ? 1u : 0u);  // 3 means rep0 - 1
-                            if (idx == 0) offset = rep0;
-                            else {
-                                uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                                t += !t;
-                                if (idx != 1) rep2 = rep1;
-                                rep1 = rep0;
-                                rep0 = t;
-                                offset = t;
-                            }
-                        }
+                        const uint32_t xl = ((el >> 12) & 15u) | ((el >> 3) & 16u), xm = ((em >> 12) & 15u) | ((em >> 3) & 16u);
+                        s.used = (eo & 63u) + xm + xl;  // offset, match-length and literal-length extras (<= 63 bits)
                         if (i0 + j + 1 < nseq) {
-                            const uint32_t nl = (el >> 8) & 0xffu, nm = (em >> 8) & 0xffu, no = (eo >> 8) & 0xffu;
+                            const uint32_t nl = (el >> 8) & 15u, nm = (em >> 8) & 15u, no = (eo >> 8) & 15u;
                             const uint32_t st3 = sq_read(L, b, s, nl + nm + no);  // <= 9 + 9 + 8 bits: LL, then ML, then OF
                             sl = (el >> 16) + (st3 >> (nm + no));
                             sm = (em >> 16) + ((st3 >> no) & ((1u << nm) - 1u));
@@ -1071,9 +1059,56 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             break;
                         }
                         if (lane == j) {
-                            ll = llen;
-                            ml = mlen;
-                            off = (uint32_t)offset;
+                            my_el = el;
+                            my_eo = eo;
+                            my_em = em;
+                            my_top = top;
+                        }
+                    }
+                    // ---- parallel part: lane j cuts sequence j's extra bits from the window and forms the values
+                    uint32_t ov = 4;
+                    if (lane < cn && lane < dec_bad) {
+                        const uint32_t oc = my_eo & 63u, mc = my_em & 63u, lc = my_el & 63u;
+                        const uint32_t xl = ((my_el >> 12) & 15u) | ((my_el >> 3) & 16u), xm = ((my_em >> 12) & 15u) | ((my_em >> 3) & 16u);
+                        const int32_t q = my_top - 64;
+                        int32_t wi = (q >> 5) - s.win0;
+                        wi = wi < 0 ? 0 : (wi > 253 ? 253 : wi);
+                        const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
+                        const uint32_t sh = (uint32_t)q & 31u;
+                        const uint64_t w64 = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
+                        const uint32_t obits = oc ? (uint32_t)(w64 >> (64u - oc)) : 0u;
+                        const uint32_t mlx = xm ? (uint32_t)((w64 << oc) >> (64u - xm)) : 0u;
+                        const uint32_t llx = xl ? (uint32_t)((w64 << (oc + xm)) >> (64u - xl)) : 0u;
+                        ov = (1u << oc) + obits;
+                        ml = (L.mltab[mc] & 0xffffffu) + mlx;
+                        ll = (L.lltab[lc] & 0xffffffu) + llx;
+                    }
+                    // ---- repeat-offset history: inherently serial, but on values read with readlane it runs on the
+                    // scalar unit; lane j picks up its offset
+                    {
+                        const uint32_t nres = cn < dec_bad ? cn : dec_bad;
+                        for (uint32_t j = 0; j < nres; j++) {
+                            const uint32_t ovj = rdlane(ov, j);
+                            const bool ll0 = rdlane(ll, j) != 0;
+                            uint32_t offset;
+                            if (ovj > 3) {
+                                offset = ovj - 3;
+                                rep2 = rep1;
+                                rep1 = rep0;
+                                rep0 = offset;
+                            } else {
+                                const uint32_t idx = ovj - (ll0 ? 1u : 0u);  // 3 means rep0 - 1
+                                if (idx == 0) offset = rep0;
+                                else {
+                                    uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                                    t += !t;
+                                    if (idx != 1) rep2 = rep1;
+                                    rep1 = rep0;
+                                    rep0 = t;
+                                    offset = t;
+                                }
+                            }
+                            if (lane == j) off = offset;
                         }
                     }
                     // ---- place the chunk ---------------------------------------------------------------
