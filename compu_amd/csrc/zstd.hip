@@ -1083,33 +1083,50 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         ml = (L.mltab[mc] & 0xffffffu) + mlx;
                         ll = (L.lltab[lc] & 0xffffffu) + llx;
                     }
-                    // ---- repeat-offset history: inherently serial, but on values read with readlane it runs on the
-                    // scalar unit; lane j picks up its offset
+                    // ---- offsets.  A sequence with a new offset (the usual case) is done in parallel; only the ones that
+                    // use the repeat-offset history are walked in order, with the history brought up to date from the
+                    // up to three new offsets in front of each (values read with readlane: scalar work).
                     {
                         const uint32_t nres = cn < dec_bad ? cn : dec_bad;
-                        for (uint32_t j = 0; j < nres; j++) {
-                            const uint32_t ovj = rdlane(ov, j);
-                            const bool ll0 = rdlane(ll, j) != 0;
-                            uint32_t offset;
-                            if (ovj > 3) {
-                                offset = ovj - 3;
+                        const bool mine = lane < nres;
+                        if (mine && ov > 3) off = ov - 3;
+                        uint64_t repm = __ballot(mine && ov <= 3);
+                        uint32_t cur = 0;  // sequences whose effect on the history is already in rep0..2
+                        auto advance = [&](uint32_t to) {  // sequences cur..to-1 all carry new offsets
+                            const uint32_t n = to - cur;
+                            if (n >= 3) {
+                                rep2 = rdlane(off, to - 3);
+                                rep1 = rdlane(off, to - 2);
+                                rep0 = rdlane(off, to - 1);
+                            } else if (n == 2) {
+                                rep2 = rep0;
+                                rep1 = rdlane(off, to - 2);
+                                rep0 = rdlane(off, to - 1);
+                            } else if (n == 1) {
                                 rep2 = rep1;
                                 rep1 = rep0;
-                                rep0 = offset;
-                            } else {
-                                const uint32_t idx = ovj - (ll0 ? 1u : 0u);  // 3 means rep0 - 1
-                                if (idx == 0) offset = rep0;
-                                else {
-                                    uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
-                                    t += !t;
-                                    if (idx != 1) rep2 = rep1;
-                                    rep1 = rep0;
-                                    rep0 = t;
-                                    offset = t;
-                                }
+                                rep0 = rdlane(off, to - 1);
+                            }
+                            cur = to;
+                        };
+                        while (repm) {
+                            const uint32_t j = (uint32_t)__ffsll((long long)repm) - 1u;
+                            repm &= repm - 1;
+                            advance(j);
+                            const uint32_t idx = rdlane(ov, j) - (rdlane(ll, j) != 0 ? 1u : 0u);  // 3 means rep0 - 1
+                            uint32_t offset = rep0;
+                            if (idx != 0) {
+                                uint32_t t = idx == 3 ? rep0 - 1 : (idx == 1 ? rep1 : rep2);
+                                t += !t;
+                                if (idx != 1) rep2 = rep1;
+                                rep1 = rep0;
+                                rep0 = t;
+                                offset = t;
                             }
                             if (lane == j) off = offset;
+                            cur = j + 1;
                         }
+                        advance(nres);
                     }
                     // ---- place the chunk ---------------------------------------------------------------
                     const uint32_t lit_incl = wave_incl_scan(ll), lit_before = lit_incl - ll;
