@@ -601,8 +601,18 @@ __device__ uint32_t wave_xxh64_low32(const uint8_t *p, uint32_t n)
     if (n >= 32) {
         uint64_t acc = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ULL : 0ULL - P1;
         const uint32_t stripes = n >> 5;
-        if (lane < 4)
-            for (uint32_t i = 0; i < stripes; i++) acc = round1(acc, rd64(32u * i + 8u * lane));
+        if (lane < 4) {
+            // the accumulator recurrence is serial; the loads are not: eight stripes are fetched at a time
+            uint32_t i = 0;
+            for (; i + 8 <= stripes; i += 8) {
+                uint64_t in[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) in[k] = rd64(32u * (i + k) + 8u * lane);
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) acc = round1(acc, in[k]);
+            }
+            for (; i < stripes; i++) acc = round1(acc, rd64(32u * i + 8u * lane));
+        }
         off = stripes << 5;
         uint64_t v[4];
         for (int k = 0; k < 4; k++) {
