@@ -1052,19 +1052,40 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t my_el = 0, my_eo = 0, my_em = 0;
                     int32_t my_top = 0;
                     for (uint32_t j = 0; j < cn; j++) {
-                        sq_load(L, b, s);
+                        // the 64 bits below the read position and the three state entries: six LDS reads in flight together
                         const int32_t top = (int32_t)s.lo + s.avail;
+                        int32_t wi = ((top - 64) >> 5) - s.win0;
+                        wi = wi < 0 ? 0 : wi;
+                        const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
                         const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
+                        const uint32_t sh = (uint32_t)(top - 64) & 31u;
+                        uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, sh), wlo = __builtin_amdgcn_alignbit(d1, d0, sh);
                         const uint32_t xl = ((el >> 12) & 15u) | ((el >> 3) & 16u), xm = ((em >> 12) & 15u) | ((em >> 3) & 16u);
-                        s.used = (eo & 63u) + xm + xl;  // offset, match-length and literal-length extras (<= 63 bits)
-                        if (i0 + j + 1 < nseq) {
-                            const uint32_t nl = (el >> 8) & 15u, nm = (em >> 8) & 15u, no = (eo >> 8) & 15u;
-                            const uint32_t st3 = sq_read(L, b, s, nl + nm + no);  // <= 9 + 9 + 8 bits: LL, then ML, then OF
+                        const uint32_t xe = (eo & 63u) + xm + xl;  // offset, match-length and literal-length extras (<= 63 bits)
+                        const bool more = i0 + j + 1 < nseq;  // the last sequence of a block updates no state
+                        const uint32_t nl = (el >> 8) & 15u, nm = (em >> 8) & 15u, no = (eo >> 8) & 15u;
+                        const uint32_t n3 = more ? nl + nm + no : 0u;  // <= 9 + 9 + 8 bits: LL, then ML, then OF
+                        int32_t x = 64 - (int32_t)(xe + n3);  // bit of the 64 at which the state bits start
+                        if (x < 0) {
+                            // rare: extras and state bits do not fit one 64-bit view; take a second one below the extras
+                            const int32_t q2 = top - (int32_t)xe - 64;
+                            int32_t w2 = (q2 >> 5) - s.win0;
+                            w2 = w2 < 0 ? 0 : w2;
+                            const uint32_t e0 = L.seqwin[w2], e1 = L.seqwin[w2 + 1], e2 = L.seqwin[w2 + 2];
+                            const uint32_t s2 = (uint32_t)q2 & 31u;
+                            whi = __builtin_amdgcn_alignbit(e2, e1, s2);
+                            wlo = __builtin_amdgcn_alignbit(e1, e0, s2);
+                            x = 64 - (int32_t)n3;
+                        }
+                        const uint32_t v = x >= 32 ? whi >> (x - 32) : __builtin_amdgcn_alignbit(whi, wlo, (uint32_t)x);
+                        const uint32_t st3 = v & ((1u << n3) - 1u);
+                        if (more) {
                             sl = (el >> 16) + (st3 >> (nm + no));
                             sm = (em >> 16) + ((st3 >> no) & ((1u << nm) - 1u));
                             so = (eo >> 16) + (st3 & ((1u << no) - 1u));
                         }
-                        if (s.avail < (int32_t)s.used) {
+                        s.avail -= (int32_t)(xe + n3);
+                        if (s.avail < 0) {
                             dec_bad = j;
                             break;
                         }
