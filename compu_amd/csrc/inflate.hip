@@ -69,10 +69,15 @@ constexpr int CL_ROOT = 7;
 #ifndef CHIP_S_BITS  // geometry overridable for experiments
 #define CHIP_S_BITS 224
 #define CHIP_XT_BITS 1024
+#define CHIP_XT_BITS_FIXED 2048  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
 #define CHIP_ROW_TOKENS 192
 #endif
 constexpr int S_BITS = CHIP_S_BITS;
 constexpr int XT_BITS = CHIP_XT_BITS;
+#ifndef CHIP_XT_BITS_FIXED
+#define CHIP_XT_BITS_FIXED CHIP_XT_BITS
+#endif
+constexpr int XT_BITS_FIXED = CHIP_XT_BITS_FIXED;
 constexpr int ROW_TOKENS = CHIP_ROW_TOKENS;
 static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0, "geometry");
 constexpr int ROW_WORDS = S_BITS / 32;  // boundary bitmap words per lane (own segment only)
@@ -722,7 +727,7 @@ enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 
 // into gout as it goes.  On return `pos` is behind the end-of-block code (status stays
 // ST_RUNNING) or status holds the reason decoding stopped.
 __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                             const uint32_t cap, int32_t &status, uint32_t *grow STAT_PARAM)
+                             const uint32_t cap, int32_t &status, uint32_t *grow, const uint32_t xt_bits STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     const LongCodes<LIT_ROOT> lcl = load_long_codes<LIT_ROOT>(L.lit_h);
@@ -744,7 +749,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         STAT_ADD(8, 1);
         // ---- walk: every lane decodes from its guessed start until it joins another lane's chain ----
         const uint32_t s = B + lane * S_BITS;
-        uint32_t lim = s + S_BITS + XT_BITS;
+        uint32_t lim = s + S_BITS + xt_bits;
         if (lim > B + 64u * S_BITS) lim = B + 64u * S_BITS;  // nobody to join behind the last segment
         uint32_t p = s, nst = 0, reason = R_LIMIT, jl = 64, aux = s;
         bool active = s < end_bit;
@@ -1090,7 +1095,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             STAT_ACC(7);
         }
         STAT_ACC(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status, grow STAT_ARG);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status, grow, tables == 1 ? (uint32_t)XT_BITS_FIXED : (uint32_t)XT_BITS STAT_ARG);
         STAT_T0();
     }
     STAT_ACC(0);
