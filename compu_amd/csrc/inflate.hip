@@ -67,7 +67,7 @@ constexpr int CL_ROOT = 7;
 // same), at most XT_BITS further.  Every lane records up to ROW_TOKENS tokens.  S_BITS is an odd number
 // of dwords so that the 64 lanes' window reads hit distinct LDS banks.
 #ifndef CHIP_S_BITS  // geometry overridable for experiments
-#define CHIP_S_BITS 224
+#define CHIP_S_BITS 288
 #define CHIP_XT_BITS 1024
 #define CHIP_XT_BITS_FIXED 2048  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
 #define CHIP_ROW_TOKENS 192
@@ -112,8 +112,6 @@ struct alignas(16) WaveLds {
             uint8_t lens[320];
         } hdr;
     };
-    uint32_t fl_heads[64];  // copy phase: owner rank+1 per match byte of a step (also path-resolve flags)
-    uint32_t fl_par[128];   // copy phase: per-match parameters by rank (also path-resolve start indices)
     uint32_t pk[64];        // k-th piece of the true stream: first row index | row (lane) << 8 | first stream index << 14
     HuffMeta lit_h, dist_h;
     uint32_t use_sub;  // long codes resolve through sub-tables living in lit_sorted/dist_sorted
@@ -815,23 +813,25 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
                 a_join += __popc(L.rows[k * 64 + jl] & below);
             }
         }
-        // lanes on the path from lane 0, by pointer doubling over the join links (links only point forward)
+        // lanes on the path from lane 0, by pointer doubling over the join links (links only point forward);
+        // the two small arrays live in the input window, which is dead once the walk is over
+        uint32_t *const res_flags = L.inbuf, *const res_start = L.inbuf + 64;
         bool on = lane == 0;
         uint32_t jump = nxt;
 #pragma unroll
         for (int r = 0; r < 6; r++) {
-            L.fl_heads[lane] = 0;
+            res_flags[lane] = 0;
             WSYNC();
-            if (on && jump < 64u) L.fl_heads[jump] = 1;
+            if (on && jump < 64u) res_flags[jump] = 1;
             WSYNC();
-            on = on || L.fl_heads[lane] != 0;
+            on = on || res_flags[lane] != 0;
             const uint32_t j2 = (uint32_t)__shfl((int)jump, (int)(jump & 63u), 64);
             jump = jump < 64u ? j2 : 64u;
             WSYNC();
         }
-        if (on && nxt < 64u) L.fl_par[nxt] = a_join;
+        if (on && nxt < 64u) res_start[nxt] = a_join;
         WSYNC();
-        const uint32_t a0 = lane == 0 ? 0u : L.fl_par[lane];
+        const uint32_t a0 = lane == 0 ? 0u : res_start[lane];
         const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
         const uint32_t incl = wave_incl_scan(cnt);
         const uint64_t onm = __ballot(on);
