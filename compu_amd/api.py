@@ -66,6 +66,8 @@ def lib():
     L.chip_memcpy_h2d.argtypes = [vp, vp, sz, vp]
     L.chip_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     L.chip_stream_sync.argtypes = [vp]
+    L.chip_trim.restype = C.c_int
+    L.chip_trim.argtypes = []
     L.chip_decoder_new.restype = vp
     L.chip_decoder_new.argtypes = [C.c_int, C.POINTER(_DecoderOpts)]
     L.chip_decode.restype = _DecodeResult
@@ -570,6 +572,13 @@ def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len
     if rc != 0:
         raise RuntimeError(f"chip_decode_batch failed: {rc}")
     return out_len, in_used, status
+
+
+def trim():
+    """Give the inflate kernel's cached token scratch of the current device back (chip_trim)."""
+    rc = lib().chip_trim()
+    if rc != 0:
+        raise RuntimeError(f"chip_trim failed: {rc}")
 
 
 def detect_batch(in_buf, in_off, in_len, kind=None, stream=None):

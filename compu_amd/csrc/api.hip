@@ -96,6 +96,7 @@ int chip_memcpy_d2h(void *dst, const void *src, size_t size, void *stream)
     return hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
 int chip_stream_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH; }
+int chip_trim(void) { return chip::release_inflate_scratch() == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH; }
 
 // ---- batched decode ------------------------------------------------------------------------
 

@@ -1187,6 +1187,24 @@ hipError_t slot_for(hipStream_t stream, LaunchSlot &out)
 }
 }  // namespace
 
+hipError_t release_inflate_scratch()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    for (auto it = g_slots.begin(); it != g_slots.end();) {
+        if (it->first.first == dev) {
+            (void)hipFree(it->second.scratch);
+            it = g_slots.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return hipSuccess;
+}
+
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;

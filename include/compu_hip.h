@@ -94,6 +94,11 @@ void chip_pinned_free(void *ptr);
 int chip_memcpy_h2d(void *dst_dev, const void *src_host, size_t size, void *stream);
 int chip_memcpy_d2h(void *dst_host, const void *src_dev, size_t size, void *stream);
 int chip_stream_sync(void *stream);
+/* The inflate kernel keeps a token scratch per (device, stream) it has been launched on: one 48 KiB slot per
+ * resident wave, about 200 MB on an MI355X, allocated at the first launch and reused.  chip_trim() waits for the
+ * current device and gives that memory back (the next launch allocates again).  No reference counterpart:
+ * zlib-ng's inflate state is ~40 KiB of host memory per decoder (src/decoder/zlib_ng.rs:29-55). */
+int chip_trim(void);
 
 /* ---- streaming decoder: mirrors decoder::Interface, src/decoder/mod.rs:160-166 --------------- */
 

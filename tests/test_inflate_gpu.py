@@ -202,3 +202,18 @@ def test_large_multiblock_streams(gpu, alice):
         if r.status == compu_amd.DecodeStatus.Finished:
             break
     assert bytes(out) == big and pos == len(comp)
+
+
+def test_trim_releases_and_reallocates_scratch(gpu):
+    """chip_trim() frees the cached token scratch; the next launch allocates it again and decodes as before."""
+    import compu_amd
+    from bench_support import synth
+
+    n = 64
+    pay = synth.payloads(n)
+    packed, offs, lens = synth.deflate_units(pay, n, kind="dynamic")
+    parts = [bytes(packed[int(offs[i]) : int(offs[i]) + int(lens[i])]) for i in range(n)]
+    for _ in range(2):
+        outs, ol, iu, st = run_batch(gpu, -15, parts, [65536] * n)
+        assert (st == 2).all() and b"".join(outs) == pay.tobytes()
+        compu_amd.trim()
