@@ -1211,6 +1211,9 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
     LaunchSlot sl;
     hipError_t e = slot_for(stream, sl);
     if (e != hipSuccess) return e;
+    // counter reset and kernel must reach the stream back to back even when several host threads launch on it
+    static std::mutex enqueue_mu;
+    std::lock_guard<std::mutex> lk(enqueue_mu);
     if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
     const uint32_t blocks = a.n < (uint32_t)sl.blocks ? a.n : (uint32_t)sl.blocks;
     hipLaunchKernelGGL(inflate_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
