@@ -313,9 +313,18 @@ __device__ __forceinline__ void win_load(WaveLds &L, InWin &w, uint32_t dw_start
 {
     WSYNC();
     w.win0 = dw_start;
-    for (uint32_t k = lane_id(); k < IN_DW; k += 64) {
-        uint32_t i = dw_start + k;
-        L.inbuf[k] = i < w.total_dw ? w.g32[i] : 0u;
+    // all loads of the window go out before the first LDS store waits for one
+    constexpr uint32_t PER_LANE = (IN_DW + 63) / 64;
+    uint32_t v[PER_LANE];
+#pragma unroll
+    for (uint32_t j = 0; j < PER_LANE; j++) {
+        const uint32_t i = dw_start + 64u * j + lane_id();
+        v[j] = i < w.total_dw ? w.g32[i] : 0u;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < PER_LANE; j++) {
+        const uint32_t k = 64u * j + lane_id();
+        if (k < IN_DW) L.inbuf[k] = v[j];
     }
     WSYNC();
 }
