@@ -112,5 +112,8 @@ __device__ __forceinline__ uint32_t wave_shr1(uint32_t v) { return dpp_or_zero<0
 
 // LDS written by some lanes of the (single) wave, read by others: order + visibility
 #define WSYNC() __syncthreads()
+// The same for LDS only: leaves global loads and stores in flight (a one-wave workgroup needs no s_barrier, LDS
+// operations of a wave complete in order; the memory clobber keeps the compiler from moving or forwarding LDS accesses)
+#define LSYNC() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 }  // namespace chip

@@ -515,10 +515,10 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             tmp[j] = 0;
             if (g < ntok) {
                 if (lane < 2) C.pmask[lane] = 0;
-                WSYNC();
+                LSYNC();  // LDS only: the token loads of the groups before stay in flight
                 const uint32_t rel = pfirst - g;
                 if (rel < 64u) atomicOr(&C.pmask[rel >> 5], 1u << (rel & 31u));
-                WSYNC();
+                LSYNC();
                 const uint64_t m = (uint64_t)C.pmask[0] | ((uint64_t)C.pmask[1] << 32);
                 const uint32_t before = (uint32_t)__popcll(__ballot(pfirst < g));
                 uint32_t k = before + (uint32_t)__popcll(m & le_mask) - 1u;
