@@ -587,12 +587,11 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             const uint32_t wi = x0 >> 5, sh = x0 & 31u;
             const bool inmap = wi < CHUNK_BYTES / 32;
             const uint32_t hw = inmap ? C.heads[wi] : 0u, wp = inmap ? C.wpre[wi] : 0u;
-            uint32_t r[4], tk[4];
+            int32_t r[4];
+            uint32_t tk[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t n = wp + (uint32_t)__popc(hw & ((2u << (sh + j)) - 1u));  // token starts at or below x0 + j
-                r[j] = n ? (n <= CHUNK_TOKENS ? n - 1u : CHUNK_TOKENS - 1u) : 0u;
-            }
+            for (int j = 0; j < 4; j++)  // token starts at or below x0 + j, minus one: -1 (a harmless read in front of the
+                r[j] = (int32_t)(wp + (uint32_t)__popc(hw & ((2u << (sh + j)) - 1u))) - 1;  // array) only for bytes below the chunk
 #pragma unroll
             for (int j = 0; j < 4; j++) tk[j] = C.tok[r[j]];
             // the step ends 256 bytes behind its dword-aligned start or at the chunk end
