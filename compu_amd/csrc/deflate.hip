@@ -186,18 +186,42 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     if (!use_stored) {
         put_uniform(L, nbits, (final ? 1u : 0u) | (1u << 1), 3);
         uint32_t skip = 0;
+        uint32_t v_next = lane < n ? ld32(g32, total_dw, mis + lane) : 0u;
         for (uint32_t base = 0; base < n; base += 64) {
             const uint32_t p = base + lane;
             const bool valid4 = p + 4 <= n;
             uint32_t mlen = 0, mdist = 0, h = 0;
-            const uint32_t v = p < n ? ld32(g32, total_dw, mis + p) : 0u;
+            const uint32_t v = v_next;  // fetched while the previous chunk was being encoded
+            v_next = p + 64 < n ? ld32(g32, total_dw, mis + p + 64) : 0u;
             if (valid4) {
                 h = (v * 2654435761u) >> (32 - HASH_BITS);
                 const uint32_t c = L.table[h];
                 if (c && p - (c - 1) <= MAX_DIST) {
                     const uint32_t q = c - 1;
                     const uint32_t lim = n - p < MAX_MATCH ? n - p : MAX_MATCH;
+                    // the first 16 bytes of both sides are fetched together (ten aligned dword loads in flight): most
+                    // candidates are decided without a second round trip to memory
                     uint32_t k = 0;
+                    {
+                        const uint32_t qi = (mis + q) >> 2, qs = ((mis + q) & 3u) * 8u, pi = (mis + p) >> 2, ps = ((mis + p) & 3u) * 8u;
+                        uint32_t qd[5], pd[5];
+#pragma unroll
+                        for (uint32_t j = 0; j < 5; j++) {
+                            qd[j] = qi + j < total_dw ? g32[qi + j] : 0u;
+                            pd[j] = pi + j < total_dw ? g32[pi + j] : 0u;
+                        }
+                        bool diff = false;
+#pragma unroll
+                        for (uint32_t j = 0; j < 4; j++) {
+                            const uint32_t x = __builtin_amdgcn_alignbit(qd[j + 1], qd[j], qs) ^ __builtin_amdgcn_alignbit(pd[j + 1], pd[j], ps);
+                            if (!diff && x) {
+                                k = 4u * j + (((uint32_t)__ffs((int)x) - 1u) >> 3);
+                                diff = true;
+                            }
+                        }
+                        if (!diff) k = 16;
+                        if (diff || k >= lim) goto measured;
+                    }
                     while (k < lim) {
                         uint32_t x = ld32(g32, total_dw, mis + q + k) ^ ld32(g32, total_dw, mis + p + k);
                         if (x) {
@@ -206,6 +230,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
                         }
                         k += 4;
                     }
+                measured:
                     if (k > lim) k = lim;
                     if (k >= MIN_MATCH) {
                         mlen = k;
@@ -213,7 +238,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
                     }
                 }
             }
-            WSYNC();  // every lookup saw the table as it stood before this chunk
+            LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the prefetch stays in flight)
             if (valid4) atomicMax(&L.table[h], p + 1);
             // greedy choice, left to right over the chunk: jump from selected match to selected match (a scalar
             // step per chosen match, not per position); everything in between is a literal
