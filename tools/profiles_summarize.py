@@ -20,10 +20,14 @@ with open(one(f"{tag}_kt/**/*kernel_stats.csv")) as f, open(os.path.join(P, f"{t
 # 2. per-dispatch durations of the inflate kernel in that run (bench order: dynamic warm-up+steps, then stored, then fixed)
 rows = [r for r in csv.DictReader(open(one(f"{tag}_kt/**/*kernel_trace.csv"))) if "inflate_kernel" in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+def _workload(i, n):  # bench order: dynamic (3 warm-up + 20 timed), then stored and fixed (each 3 + 5)
+    return "dynamic" if i < 23 else ("stored" if i < 31 else "fixed") if n == 39 else ""
+
+
 with open(os.path.join(P, f"{tag}_inflate_dispatches.csv"), "w") as o:
-    o.write("dispatch_index,duration_ms\n")
+    o.write("dispatch_index,duration_ms,workload\n")
     for i, r in enumerate(rows):
-        o.write(f"{i},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:.4f}\n")
+        o.write(f"{i},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:.4f},{_workload(i, len(rows))}\n")
 # 3. PMC passes: counters per inflate dispatch; bench order with --steps 3 --warmup 1 is dynamic x4, stored x4, fixed x4
 traffic = {}
 for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
