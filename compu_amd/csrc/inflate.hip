@@ -460,8 +460,8 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 // earlier -- from the chunk's own output, which is assembled in LDS, or from HBM when the source lies
 // below the chunk -- and the finished chunk goes out with coalesced dword stores.
 #ifndef CHIP_CHUNK_GROUPS
-#define CHIP_CHUNK_GROUPS 5
-#define CHIP_CHUNK_BYTES 1024
+#define CHIP_CHUNK_GROUPS 6
+#define CHIP_CHUNK_BYTES 1536
 #endif
 constexpr uint32_t CHUNK_GROUPS = CHIP_CHUNK_GROUPS;
 constexpr uint32_t CHUNK_TOKENS = 64 * CHUNK_GROUPS;
