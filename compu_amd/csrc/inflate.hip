@@ -758,6 +758,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
         uint32_t lim = s + S_BITS + xt_bits;
         if (lim > B + 64u * S_BITS) lim = B + 64u * S_BITS;  // nobody to join behind the last segment
         uint32_t p = s, nst = 0, reason = R_LIMIT, jl = 64, aux = s;
+        uint32_t segc = lane, off = 0;  // p = B + segc * S_BITS + off
         bool active = s < end_bit;
         while (__any(active)) {
             STAT_ADD(11, 1);
@@ -767,8 +768,8 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // the boundary at p: marked in the lane's own row, looked up in the row of the segment's owner elsewhere
-                const uint32_t rel = active ? p - B : lane * S_BITS;
-                const uint32_t seg = rel / S_BITS, off = rel - seg * S_BITS;
+                // (segment and offset inside it are carried along: no division; a stopped lane keeps a harmless index)
+                const uint32_t seg = segc & 63u;
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&L.rows[(off >> 5) * 64 + seg], (active && seg == lane) ? bit : 0u);
                 const bool joined = active && seg != lane && (old & bit);
@@ -801,6 +802,10 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
                 }
                 nst += go ? 1u : 0u;
                 p += go ? tb : 0u;
+                off += go ? tb : 0u;
+                const bool wrap = off >= (uint32_t)S_BITS;
+                off -= wrap ? (uint32_t)S_BITS : 0u;
+                segc += wrap ? 1u : 0u;
                 active = go && p < lim && nst < (uint32_t)ROW_TOKENS;
                 if (go && !active) aux = p;  // reason stays R_LIMIT: the chain simply ends here
             }
