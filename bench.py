@@ -187,13 +187,39 @@ def cpu_baseline(packed, offs, lens, n_sample, threads):
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
     assert bad == 0 and (out_len == UNIT).all()
-    return {
+    res = {
         "value": round(n * UNIT / best / 1e9, 3),
         "unit": "GB/s",
         "cores": threads,
         "kind": "port",
         "sample": f"first {n} units of the same batch ({n * UNIT / 2**20:.0f} MiB out), oracle/oracle_inflate.c, one decoder per thread reset per unit, output pre-touched, best of 3",
     }
+    # for orientation only (not the baseline): the host's system zlib on a slice of the same sample, same thread count
+    try:
+        import zlib
+        from concurrent.futures import ThreadPoolExecutor
+
+        m = min(n, 16384)
+        parts = [bytes(packed[int(offs[i]) : int(offs[i]) + int(lens[i])]) for i in range(m)]
+
+        def work(rng):
+            tot = 0
+            for i in rng:
+                tot += len(zlib.decompressobj(-15).decompress(parts[i]))
+            return tot
+
+        chunks = [range(k, m, threads) for k in range(threads)]
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(work, chunks))  # warm
+            t0 = time.perf_counter()
+            tot = sum(ex.map(work, chunks))
+            dt = time.perf_counter() - t0
+        assert tot == m * UNIT
+        res["system_zlib"] = {"value": round(tot / dt / 1e9, 3), "unit": "GB/s", "threads": threads, "version": zlib.ZLIB_RUNTIME_VERSION,
+                              "sample": f"first {m} units through Python's zlib.decompressobj(-15) (GIL released inside inflate)"}
+    except Exception as e:  # the figure is optional
+        res["system_zlib"] = {"error": str(e)}
+    return res
 
 
 def main():
