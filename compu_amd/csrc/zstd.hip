@@ -30,7 +30,8 @@ __device__ const int8_t LL_DEF[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 
 __device__ const int8_t OF_DEF[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
 __device__ const int8_t ML_DEF[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 
-// FSE decode entry: [7:0] symbol, [15:8] number of bits to read, [31:16] baseline of the next state
+// FSE decode entry: [5:0] symbol, [9:6] number of bits to read, [14:10] extra bits the symbol's code carries (LL / ML
+// tables, filled in after the build), [31:16] baseline of the next state
 template <int N>
 struct FseTabN {
     uint32_t e[N];
@@ -456,7 +457,7 @@ __device__ int fse_build(ZLds &L, FseView t, int nsym, int al)
             uint32_t ns = L.next[s];
             L.next[s] = (uint16_t)(ns + 1);
             uint32_t nb = (uint32_t)al - (31u - (uint32_t)__clz((int)ns));
-            t.e[u] = s | (nb << 8) | ((((ns << nb) - (uint32_t)size) & 0xffffu) << 16);
+            t.e[u] = s | (nb << 6) | ((((ns << nb) - (uint32_t)size) & 0xffffu) << 16);
         }
         *t.al = (uint32_t)al;
         *t.valid = 1;
@@ -556,21 +557,21 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
         for (;;) {
             if (nw > 253) return -1;
             uint32_t e1 = L.wt.e[s1];
-            if (w) L.weights[nw] = (uint8_t)e1;
+            if (w) L.weights[nw] = (uint8_t)(e1 & 63u);
             nw++;
-            s1 = (e1 >> 16) + bb_read(b, s, (e1 >> 8) & 0xffu);
+            s1 = (e1 >> 16) + bb_read(b, s, (e1 >> 6) & 15u);
             if (s.avail < 0) {
-                if (w) L.weights[nw] = (uint8_t)L.wt.e[s2];
+                if (w) L.weights[nw] = (uint8_t)(L.wt.e[s2] & 63u);
                 nw++;
                 break;
             }
             if (nw > 253) return -1;
             uint32_t e2 = L.wt.e[s2];
-            if (w) L.weights[nw] = (uint8_t)e2;
+            if (w) L.weights[nw] = (uint8_t)(e2 & 63u);
             nw++;
-            s2 = (e2 >> 16) + bb_read(b, s, (e2 >> 8) & 0xffu);
+            s2 = (e2 >> 16) + bb_read(b, s, (e2 >> 6) & 15u);
             if (s.avail < 0) {
-                if (w) L.weights[nw] = (uint8_t)L.wt.e[s1];
+                if (w) L.weights[nw] = (uint8_t)(L.wt.e[s1] & 63u);
                 nw++;
                 break;
             }
@@ -1011,14 +1012,13 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     } else if (!*t.valid) ZFAIL(ZSTD_E_CORRUPTION);
                     if (mode != 3 && k != 1) {
                         // a freshly built LL / ML table also carries, per state, how many extra bits its code reads
-                        // ([15:12] and bit 7): the serial state chain then needs no second lookup to find the next state's bits
+                        // ([14:10]): the serial state chain then needs no second lookup to find the next state's bits
                         WSYNC();
                         const uint32_t *xt = k == 0 ? L.lltab : L.mltab;
                         const uint32_t size = 1u << *t.al;
                         for (uint32_t u = lane; u < size; u += 64) {
                             const uint32_t e = t.e[u];
-                            const uint32_t xb = xt[e & 63u] >> 24;
-                            t.e[u] = e | ((xb & 15u) << 12) | ((xb >> 4) << 7);
+                            t.e[u] = e | ((xt[e & 63u] >> 24) << 10);
                         }
                     }
                 }
@@ -1060,10 +1060,10 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
                         const uint32_t sh = (uint32_t)(top - 64) & 31u;
                         uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, sh), wlo = __builtin_amdgcn_alignbit(d1, d0, sh);
-                        const uint32_t xl = ((el >> 12) & 15u) | ((el >> 3) & 16u), xm = ((em >> 12) & 15u) | ((em >> 3) & 16u);
+                        const uint32_t xl = (el >> 10) & 31u, xm = (em >> 10) & 31u;
                         const uint32_t xe = (eo & 63u) + xm + xl;  // offset, match-length and literal-length extras (<= 63 bits)
                         const bool more = i0 + j + 1 < nseq;  // the last sequence of a block updates no state
-                        const uint32_t nl = (el >> 8) & 15u, nm = (em >> 8) & 15u, no = (eo >> 8) & 15u;
+                        const uint32_t nl = (el >> 6) & 15u, nm = (em >> 6) & 15u, no = (eo >> 6) & 15u;
                         const uint32_t n3 = more ? nl + nm + no : 0u;  // <= 9 + 9 + 8 bits: LL, then ML, then OF
                         int32_t x = 64 - (int32_t)(xe + n3);  // bit of the 64 at which the state bits start
                         if (x < 0) {
@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t ov = 4;
                     if (lane < cn && lane < dec_bad) {
                         const uint32_t oc = my_eo & 63u, mc = my_em & 63u, lc = my_el & 63u;
-                        const uint32_t xl = ((my_el >> 12) & 15u) | ((my_el >> 3) & 16u), xm = ((my_em >> 12) & 15u) | ((my_em >> 3) & 16u);
+                        const uint32_t xl = (my_el >> 10) & 31u, xm = (my_em >> 10) & 31u;
                         const int32_t q = my_top - 64;
                         int32_t wi = (q >> 5) - s.win0;
                         wi = wi < 0 ? 0 : (wi > 253 ? 253 : wi);
