@@ -41,8 +41,9 @@ struct Stats { unsigned long long *st_; unsigned long long &st_t0_; };
 #define STAT_PARAM
 #define STAT_ARG
 #endif
-// stat slots: 0 header+tables, 1 window load, 2 pass1, 3 resolve, 4 pass2, 5 flush, 6 checksum/trailer,
-// 8 super-rounds, 9 sum of valid lanes, 10 tokens, 11 pass1 iterations, 12 pass2 iterations, 13 flush groups, 14 match steps, 15 fix-up rounds
+// stat slots (cycles): 0 other header work, 1 window load, 2 walk, 3 path resolve, 4 code lengths (+ block header), 5 table
+// build, 6 checksum/trailer, 7 sub-tables, 16 chunk fetch + set-up, 17 copy steps + chunk store, 20 rest of the flush;
+// (counts): 8 super-rounds, 9 lanes on the path, 10 tokens, 11 walk loop trips (4 tokens each), 13 chunks, 14 copy steps
 
 // ---- table entry format (shared by lit/len, distance and code-length tables) -------------------
 // [3:0] code length (0 = longer than the root table, resolve canonically)
