@@ -9,9 +9,10 @@
 //   --> canonical-Huffman LUTs in LDS --> 64 lanes decode 64 segments of the bitstream at once, each
 //   from a guessed start, recording tokens (literal | len,dist) in the wave's scratch rows (HBM/L2)
 //   and joining the lane whose segment they run into --> the chain of joins from lane 0 is the true
-//   token stream --> wave prefix sum of token output lengths --> byte scatter of literals and
-//   cooperative LZ77 copies straight into the unit's output range in HBM (the window is the output
-//   itself, L2-resident for a 64 KiB unit).
+//   token stream --> executed a chunk (<= 1.5 KB of output) at a time: token output offsets by wave
+//   prefix sum, the owner of every output byte by bitmap popcount, four bytes per lane per step,
+//   assembled in LDS and stored coalesced into the unit's output range in HBM (the LZ77 window is
+//   the output itself).
 // The grid is persistent: waves take units from a counter, so the token scratch is one slot per
 // resident wave, not per unit.
 #include <cstddef>
