@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     ZlibOptions,
     ZstdOptions,
     decode_batch,
+    decode_batch_host,
     trim,
     decoder_interface,
     detect_batch,

@@ -66,6 +66,8 @@ def lib():
     L.chip_memcpy_h2d.argtypes = [vp, vp, sz, vp]
     L.chip_memcpy_d2h.argtypes = [vp, vp, sz, vp]
     L.chip_stream_sync.argtypes = [vp]
+    L.chip_decode_batch_host.restype = C.c_int
+    L.chip_decode_batch_host.argtypes = [C.c_int, C.c_size_t] + [vp] * 9 + [C.c_int, C.c_size_t]
     L.chip_trim.restype = C.c_int
     L.chip_trim.argtypes = []
     L.chip_decoder_new.restype = vp
@@ -571,6 +573,26 @@ def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len
                                  _dp(out_len), _dp(in_used), _dp(status), _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"chip_decode_batch failed: {rc}")
+    return out_len, in_used, status
+
+
+def decode_batch_host(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, device=-1, slice_bytes=0):
+    """chip_decode_batch_host over numpy arrays in host memory (pinned or not): returns (out_len, in_used, status)."""
+    import numpy as np
+
+    n = len(in_len)
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
+    out_len = np.zeros(n, np.uint32)
+    in_used = np.zeros(n, np.uint32)
+    status = np.zeros(n, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = lib().chip_decode_batch_host(int(fmt), n, p(in_buf), p(in_off), p(in_len), p(out_buf), p(out_off), p(out_cap), p(out_len), p(in_used),
+                                      p(status), int(device), int(slice_bytes))
+    if rc != 0:
+        raise RuntimeError(f"chip_decode_batch_host failed: {rc}")
     return out_len, in_used, status
 
 

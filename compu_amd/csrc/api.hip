@@ -141,6 +141,142 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
 
+// Host-memory variant: slices of consecutive units alternate between two streams (H2D -> kernel -> D2H each).
+int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                           uint32_t *in_used, int32_t *status, int device, size_t slice_bytes)
+{
+    if (n == 0) return CHIP_OK;
+    if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !in_used || !status)
+        return CHIP_E_INVALID;
+    if (!device_ok()) return CHIP_E_NO_DEVICE;
+    if (device >= 0 && hipSetDevice(device) != hipSuccess) return CHIP_E_INVALID;
+    if (slice_bytes == 0) slice_bytes = (size_t)256 << 20;
+    struct Lane {  // one of the two pipelines
+        hipStream_t stream = nullptr;
+        uint8_t *d_in = nullptr, *d_out = nullptr;
+        size_t in_cap = 0, out_cap = 0;
+        uint8_t *d_arr = nullptr;  // per-unit arrays of the slice, device side
+        uint8_t *h_arr = nullptr;  // the same, pinned host side
+        size_t arr_units = 0;
+        size_t i0 = 0, i1 = 0;     // slice in flight (i1 == i0: none)
+        uint64_t out_lo = 0;
+    } lanes[2];
+    int rc = CHIP_OK;
+    // per unit: in_off u64, out_off u64, in_len u32, out_cap u32, out_len u32, in_used u32, status i32 = 36 bytes
+    auto arr_bytes = [](size_t units) { return units * 36 + 64; };
+    auto reserve = [&](Lane &ln, size_t in_need, size_t out_need, size_t units) -> bool {
+        if (in_need > ln.in_cap) {
+            chip_device_free(ln.d_in);
+            ln.in_cap = in_need + (in_need >> 2) + 4096;
+            if (!(ln.d_in = (uint8_t *)chip_device_alloc(ln.in_cap))) return false;
+        }
+        if (out_need > ln.out_cap) {
+            chip_device_free(ln.d_out);
+            ln.out_cap = out_need + (out_need >> 2) + 4096;
+            if (!(ln.d_out = (uint8_t *)chip_device_alloc(ln.out_cap))) return false;
+        }
+        if (units > ln.arr_units) {
+            chip_device_free(ln.d_arr);
+            chip_pinned_free(ln.h_arr);
+            ln.arr_units = units + (units >> 2) + 64;
+            ln.d_arr = (uint8_t *)chip_device_alloc(arr_bytes(ln.arr_units));
+            ln.h_arr = (uint8_t *)chip_pinned_alloc(arr_bytes(ln.arr_units));
+            if (!ln.d_arr || !ln.h_arr) return false;
+        }
+        return true;
+    };
+    // results of the slice a lane has in flight -> caller's arrays (after its stream has drained)
+    auto collect = [&](Lane &ln) -> bool {
+        if (ln.i1 == ln.i0) return true;
+        if (hipStreamSynchronize(ln.stream) != hipSuccess) return false;
+        const size_t m = ln.i1 - ln.i0;
+        const uint32_t *r = (const uint32_t *)(ln.h_arr + m * 24);
+        memcpy(out_len + ln.i0, r, m * 4);
+        memcpy(in_used + ln.i0, r + m, m * 4);
+        memcpy(status + ln.i0, r + 2 * m, m * 4);
+        ln.i1 = ln.i0;
+        return true;
+    };
+    for (int k = 0; k < 2 && rc == CHIP_OK; k++)
+        if (hipStreamCreateWithFlags(&lanes[k].stream, hipStreamNonBlocking) != hipSuccess) rc = CHIP_E_LAUNCH;
+    size_t i = 0;
+    int turn = 0;
+    while (rc == CHIP_OK && i < n) {
+        // next slice: consecutive units until the byte budget is reached
+        size_t j = i;
+        uint64_t in_lo = ~0ull, in_hi = 0, o_lo = ~0ull, o_hi = 0, budget = 0;
+        while (j < n) {
+            const uint64_t a0 = in_off[j], a1 = a0 + in_len[j], b0 = out_off[j], b1 = b0 + out_cap[j];
+            if (j > i && budget + in_len[j] + out_cap[j] > slice_bytes) break;
+            budget += (uint64_t)in_len[j] + out_cap[j];
+            in_lo = a0 < in_lo ? a0 : in_lo;
+            in_hi = a1 > in_hi ? a1 : in_hi;
+            o_lo = b0 < o_lo ? b0 : o_lo;
+            o_hi = b1 > o_hi ? b1 : o_hi;
+            j++;
+        }
+        Lane &ln = lanes[turn];
+        turn ^= 1;
+        if (!collect(ln)) {
+            rc = CHIP_E_LAUNCH;
+            break;
+        }
+        const uint64_t in_base_lo = in_lo & ~3ull;  // keep the units' alignment relative to a dword-aligned device base
+        const size_t in_span = (size_t)(in_hi - in_base_lo), out_span = (size_t)(o_hi - o_lo), m = j - i;
+        if (!reserve(ln, ((in_span + 3) & ~(size_t)3) + 16, out_span + 16, m)) {
+            rc = CHIP_E_NOMEM;
+            break;
+        }
+        // per-unit arrays rebased to the slice
+        uint64_t *h_in_off = (uint64_t *)ln.h_arr, *h_out_off = h_in_off + m;
+        uint32_t *h_in_len = (uint32_t *)(h_out_off + m), *h_out_cap = h_in_len + m;
+        for (size_t u = 0; u < m; u++) {
+            h_in_off[u] = in_off[i + u] - in_base_lo;
+            h_out_off[u] = out_off[i + u] - o_lo;
+            h_in_len[u] = in_len[i + u];
+            h_out_cap[u] = out_cap[i + u];
+        }
+        uint64_t *d_in_off = (uint64_t *)ln.d_arr, *d_out_off = d_in_off + m;
+        uint32_t *d_in_len = (uint32_t *)(d_out_off + m), *d_out_cap = d_in_len + m, *d_res = d_out_cap + m;
+        bool ok = hipMemcpyAsync(ln.d_arr, ln.h_arr, m * 24, hipMemcpyHostToDevice, ln.stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(ln.d_in, (const uint8_t *)in_base + in_base_lo, in_span, hipMemcpyHostToDevice, ln.stream) == hipSuccess;
+        ok = ok && chip_decode_batch(format, m, ln.d_in, d_in_off, d_in_len, ln.d_out, d_out_off, d_out_cap, d_res, d_res + m,
+                                     (int32_t *)(d_res + 2 * m), ln.stream) == CHIP_OK;
+        ok = ok && hipMemcpyAsync((uint8_t *)out_base + o_lo, ln.d_out, out_span, hipMemcpyDeviceToHost, ln.stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(ln.h_arr + m * 24, d_res, m * 12, hipMemcpyDeviceToHost, ln.stream) == hipSuccess;
+        if (!ok) {
+            rc = CHIP_E_LAUNCH;
+            break;
+        }
+        ln.i0 = i;
+        ln.i1 = j;
+        i = j;
+    }
+    for (int k = 0; k < 2; k++) {
+        Lane &ln = lanes[k];
+        if (ln.stream) {
+            if (rc == CHIP_OK) {
+                if (!collect(ln)) rc = CHIP_E_LAUNCH;
+            } else {
+                (void)hipStreamSynchronize(ln.stream);
+            }
+        }
+    }
+    for (int k = 0; k < 2; k++) {
+        Lane &ln = lanes[k];
+        if (ln.stream) {
+            chip::release_inflate_scratch_of(ln.stream);  // the stream's token scratch goes with it
+            (void)hipStreamDestroy(ln.stream);
+        }
+        chip_device_free(ln.d_in);
+        chip_device_free(ln.d_out);
+        chip_device_free(ln.d_arr);
+        chip_pinned_free(ln.h_arr);
+    }
+    return rc;
+}
+
 // Detection::detect, src/decoder/mod.rs:28-114 (including the fall-through of the 0x68 arm,
 // src/decoder/mod.rs:80-82, which makes `68 xx` zlib headers come out as Unknown).
 int chip_detect(const uint8_t *b, size_t len)

@@ -42,6 +42,7 @@ struct BatchArgs {
 // launchers (each only enqueues on `stream`)
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);
 hipError_t release_inflate_scratch();  // frees the cached token scratch of the current device (after a device sync)
+void release_inflate_scratch_of(hipStream_t stream);  // the same for one (drained) stream of the current device
 hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_t stream);
 hipError_t launch_detect(size_t n, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
                          hipStream_t stream);

@@ -1220,6 +1220,18 @@ hipError_t release_inflate_scratch()
     return hipSuccess;
 }
 
+void release_inflate_scratch_of(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    auto it = g_slots.find({dev, stream});
+    if (it != g_slots.end()) {
+        (void)hipFree(it->second.scratch);
+        g_slots.erase(it);
+    }
+}
+
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;

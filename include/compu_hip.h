@@ -147,6 +147,21 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
                       void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
                       uint32_t *in_used, int32_t *status, void *stream);
 
+/*
+ * The same for data that starts and ends in HOST memory (SURVEY.md sec. 8b "pinned-host variant", 8e): every
+ * pointer is a host pointer (hipHostMalloc / chip_pinned_alloc memory lets the copies run asynchronously; pageable
+ * memory works but serialises them).  The units are cut into slices of consecutive indices (about `slice_bytes` of
+ * input + output each, 0 = 256 MiB); slices alternate between two HIP streams, each running H2D -> kernel -> D2H for
+ * its slice, so the copies of one slice overlap the kernel of the other.  Offsets are relative to in_base /
+ * out_base as in chip_decode_batch; a slice copies the byte range its units span, so units packed in index order
+ * (the usual layout) move no extra bytes; the host output range of a slice is written as a whole, so bytes between
+ * out_len[i] and out_cap[i] end up unspecified.  Returns when everything has arrived in host memory.
+ * No reference counterpart: compu's decode loop is the host-memory path (src/decoder/mod.rs:323-335).
+ */
+int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                           uint32_t *in_used, int32_t *status, int device, size_t slice_bytes);
+
 /* Detection::detect src/decoder/mod.rs:28-114 on the first bytes of each unit; kind[i] gets a
  * CHIP_DETECT_* value.  Host form and batched device form. */
 int chip_detect(const uint8_t *bytes, size_t len);

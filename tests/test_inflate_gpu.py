@@ -217,3 +217,45 @@ def test_trim_releases_and_reallocates_scratch(gpu):
         outs, ol, iu, st = run_batch(gpu, -15, parts, [65536] * n)
         assert (st == 2).all() and b"".join(outs) == pay.tobytes()
         compu_amd.trim()
+
+
+def test_host_memory_variant_matches_device_variant(gpu, alice):
+    """chip_decode_batch_host: units in host memory, sliced over two streams; same results as the device call
+    (several slices, units of every block type, a truncated and a corrupt unit, zstd and Detection routing)."""
+    import compu_amd
+    import zstd_ref
+
+    rnd = random.Random(4)
+    z = zstd_ref.load()
+    datas, parts = [], []
+    for it in range(200):
+        n = rnd.choice([0, 100, 5000, 65536, 70000])
+        data = _mk(rnd.randrange(5), n, rnd, alice)
+        k = rnd.randrange(3)
+        if k == 0:
+            co = zlib.compressobj(rnd.choice([0, 1, 6]), zlib.DEFLATED, 31)
+            comp = co.compress(data) + co.flush()
+        elif k == 1:
+            co = zlib.compressobj(6, zlib.DEFLATED, 15)
+            comp = co.compress(data) + co.flush()
+        else:
+            comp = zstd_ref.compress(z, data, 3)
+        if it == 17:
+            comp = comp[: len(comp) // 2]
+        if it == 33 and len(comp) > 20:
+            comp = comp[:15] + bytes([comp[15] ^ 0x55]) + comp[16:]
+        datas.append(data)
+        parts.append(comp)
+    caps = [len(d) + 64 for d in datas]
+    outs_d, ol_d, iu_d, st_d = run_batch(gpu, 0, parts, caps, check_tail=False)  # CHIP_FMT_DETECT on the device path
+    buf, offs, lens = _pack(parts)
+    caps_a = np.asarray(caps, dtype=np.uint32)
+    ooff = np.zeros(len(parts), dtype=np.uint64)
+    ooff[1:] = np.cumsum(((caps_a[:-1].astype(np.uint64) + 15) & ~np.uint64(15)))
+    out = np.zeros(int(ooff[-1] + caps_a[-1]) + 16, np.uint8)
+    ol, iu, st = compu_amd.decode_batch_host(0, buf, offs.astype(np.uint64), lens.astype(np.uint32), out, ooff, caps_a, slice_bytes=1 << 20)
+    assert (st == st_d).all() and (ol == ol_d).all() and (iu == iu_d).all()
+    for i in range(len(parts)):
+        assert bytes(out[int(ooff[i]) : int(ooff[i]) + int(ol[i])]) == outs_d[i], i
+        if st[i] == 2:
+            assert outs_d[i] == datas[i]
