@@ -186,42 +186,70 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     if (!use_stored) {
         put_uniform(L, nbits, (final ? 1u : 0u) | (1u << 1), 3);
         uint32_t skip = 0;
+        // Two chunks are in flight: while chunk c is measured, chosen and emitted, chunk c+1 has already done its
+        // table lookups and updates (they depend on hashes and positions only, never on what matched) and its
+        // candidate bytes are on their way from memory.  Every lane issues the same eleven loads per chunk (lanes
+        // without a candidate compare their own position with itself) so that waiting for chunk c's bytes can leave
+        // chunk c+1's in flight.
+        struct Cand {
+            uint32_t v, q, qd[5], pd[5];
+            bool has;
+        };
+        const uint32_t last_dw = total_dw ? total_dw - 1u : 0u;
         uint32_t v_next = lane < n ? ld32(g32, total_dw, mis + lane) : 0u;
-        for (uint32_t base = 0; base < n; base += 64) {
+        auto lookup = [&](Cand &c, uint32_t base) {
             const uint32_t p = base + lane;
-            const bool valid4 = p + 4 <= n;
-            uint32_t mlen = 0, mdist = 0, h = 0;
-            const uint32_t v = v_next;  // fetched while the previous chunk was being encoded
-            v_next = p + 64 < n ? ld32(g32, total_dw, mis + p + 64) : 0u;
+            const bool valid4 = p + 4 <= n && base < n;
+            c.v = v_next;
+            {
+                const uint32_t off = mis + p + 64u, i = off >> 2;  // the chunk after this one, clamped into the unit
+                const uint32_t d0 = g32[i < last_dw ? i : last_dw], d1 = g32[i + 1 < last_dw ? i + 1 : last_dw];
+                v_next = p + 64 < n ? __builtin_amdgcn_alignbit(i + 1 < total_dw ? d1 : 0u, i < total_dw ? d0 : 0u, (off & 3u) * 8u) : 0u;
+            }
+            uint32_t h = 0;
+            c.has = false;
+            c.q = p;
             if (valid4) {
-                h = (v * 2654435761u) >> (32 - HASH_BITS);
-                const uint32_t c = L.table[h];
-                if (c && p - (c - 1) <= MAX_DIST) {
-                    const uint32_t q = c - 1;
-                    const uint32_t lim = n - p < MAX_MATCH ? n - p : MAX_MATCH;
-                    // the first 16 bytes of both sides are fetched together (ten aligned dword loads in flight): most
-                    // candidates are decided without a second round trip to memory
-                    uint32_t k = 0;
-                    {
-                        const uint32_t qi = (mis + q) >> 2, qs = ((mis + q) & 3u) * 8u, pi = (mis + p) >> 2, ps = ((mis + p) & 3u) * 8u;
-                        uint32_t qd[5], pd[5];
+                h = (c.v * 2654435761u) >> (32 - HASH_BITS);
+                const uint32_t t = L.table[h];
+                if (t && p - (t - 1) <= MAX_DIST) {
+                    c.has = true;
+                    c.q = t - 1;
+                }
+            }
+            const uint32_t qi = (mis + c.q) >> 2, pi = (mis + p) >> 2;
 #pragma unroll
-                        for (uint32_t j = 0; j < 5; j++) {
-                            qd[j] = qi + j < total_dw ? g32[qi + j] : 0u;
-                            pd[j] = pi + j < total_dw ? g32[pi + j] : 0u;
-                        }
-                        bool diff = false;
+            for (uint32_t j = 0; j < 5; j++) {
+                c.qd[j] = g32[qi + j < last_dw ? qi + j : last_dw];
+                c.pd[j] = g32[pi + j < last_dw ? pi + j : last_dw];
+            }
+            LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the loads stay in flight)
+            if (valid4) atomicMax(&L.table[h], p + 1);
+        };
+        Cand cur;
+        lookup(cur, 0);
+        for (uint32_t base = 0; base < n; base += 64) {
+            Cand nxt;
+            lookup(nxt, base + 64);  // past the end this is an empty chunk: same loads, nothing looked up
+            const uint32_t p = base + lane;
+            uint32_t mlen = 0, mdist = 0;
+            const uint32_t v = cur.v;
+            if (cur.has) {
+                const uint32_t q = cur.q;
+                const uint32_t lim = n - p < MAX_MATCH ? n - p : MAX_MATCH;
+                // the first 16 bytes of both sides arrived together: most candidates are decided right here
+                uint32_t k = 16;
+                const uint32_t qs = ((mis + q) & 3u) * 8u, ps = ((mis + p) & 3u) * 8u;
+                bool diff = false;
 #pragma unroll
-                        for (uint32_t j = 0; j < 4; j++) {
-                            const uint32_t x = __builtin_amdgcn_alignbit(qd[j + 1], qd[j], qs) ^ __builtin_amdgcn_alignbit(pd[j + 1], pd[j], ps);
-                            if (!diff && x) {
-                                k = 4u * j + (((uint32_t)__ffs((int)x) - 1u) >> 3);
-                                diff = true;
-                            }
-                        }
-                        if (!diff) k = 16;
-                        if (diff || k >= lim) goto measured;
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t x = __builtin_amdgcn_alignbit(cur.qd[j + 1], cur.qd[j], qs) ^ __builtin_amdgcn_alignbit(cur.pd[j + 1], cur.pd[j], ps);
+                    if (!diff && x) {
+                        k = 4u * j + (((uint32_t)__ffs((int)x) - 1u) >> 3);
+                        diff = true;
                     }
+                }
+                if (!diff) {
                     while (k < lim) {
                         uint32_t x = ld32(g32, total_dw, mis + q + k) ^ ld32(g32, total_dw, mis + p + k);
                         if (x) {
@@ -230,16 +258,13 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
                         }
                         k += 4;
                     }
-                measured:
-                    if (k > lim) k = lim;
-                    if (k >= MIN_MATCH) {
-                        mlen = k;
-                        mdist = p - q;
-                    }
+                }
+                if (k > lim) k = lim;
+                if (k >= MIN_MATCH) {
+                    mlen = k;
+                    mdist = p - q;
                 }
             }
-            LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the prefetch stays in flight)
-            if (valid4) atomicMax(&L.table[h], p + 1);
             // greedy choice, left to right over the chunk: jump from selected match to selected match (a scalar
             // step per chosen match, not per position); everything in between is a literal
             const uint32_t lim64 = n - base < 64 ? n - base : 64;
@@ -270,6 +295,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
             }
             nbits += rdlane(incl, 63);
             if (nbits > (uint32_t)(OUT_DW - 64) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
+            cur = nxt;
         }
         put_uniform(L, nbits, 0, 7);  // end of block
         if (!final) {
