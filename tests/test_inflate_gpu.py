@@ -259,3 +259,40 @@ def test_host_memory_variant_matches_device_variant(gpu, alice):
         assert bytes(out[int(ooff[i]) : int(ooff[i]) + int(ol[i])]) == outs_d[i], i
         if st[i] == 2:
             assert outs_d[i] == datas[i]
+
+
+def test_concurrent_launches_from_two_host_threads(gpu):
+    """Two host threads launch batches on the same (default) stream at the same time: the persistent kernel's unit
+    counter is reset and consumed per launch, so neither batch may lose or repeat units."""
+    import threading
+
+    import compu_amd
+    from bench_support import synth
+
+    n = 512
+    pay = synth.payloads(n)
+    packed, offs, lens = synth.deflate_units(pay, n, kind="dynamic")
+    dev = "cuda:0"
+    d_in = gpu.from_numpy(packed).to(dev)
+    d_off = gpu.from_numpy(offs.astype(np.int64)).to(dev)
+    d_len = gpu.from_numpy(lens.astype(np.int32)).to(dev)
+    ooff = gpu.arange(n, dtype=gpu.int64, device=dev) * 65536
+    caps = gpu.full((n,), 65536, dtype=gpu.int32, device=dev)
+    outs = [gpu.zeros(n * 65536, dtype=gpu.uint8, device=dev) for _ in range(2)]
+    res = [None, None]
+    want = gpu.from_numpy(pay).to(dev)
+
+    def work(k):
+        for _ in range(20):
+            res[k] = compu_amd.decode_batch(-15, d_in, d_off, d_len, outs[k], ooff, caps)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    gpu.cuda.synchronize()
+    for k in range(2):
+        ol, iu, st = res[k]
+        assert bool((st == 2).all()) and bool((ol == 65536).all())
+        assert gpu.equal(outs[k], want)
