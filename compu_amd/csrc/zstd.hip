@@ -490,32 +490,71 @@ __device__ int huf_build(ZLds &L, int n)
 {
     WSYNC();
     const uint32_t lane = lane_id();
-    uint32_t total = 0;
+    // lane l keeps the weights of symbols l, 64 + l, 128 + l, 192 + l; per-weight symbol counts come from ballots, so
+    // nothing below walks the 256 symbols one LDS read at a time
+    uint32_t w[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) w[c] = 64 * c + (int)lane < n ? (uint32_t)L.weights[64 * c + lane] : 0u;
     bool bad = false;
-    for (int i = 0; i < n; i++) {
-        uint32_t wv = L.weights[i];
-        if (wv > 11) bad = true;
-        if (wv) total += 1u << (wv - 1);
+#pragma unroll
+    for (int c = 0; c < 4; c++) bad = bad || w[c] > 11;
+    if (__any(bad)) return -1;
+    uint32_t cntw[12];
+    uint32_t total = 0;
+#pragma unroll
+    for (uint32_t wt = 1; wt <= 11; wt++) {
+        uint32_t cn = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) cn += (uint32_t)__popcll(__ballot(w[c] == wt));
+        cntw[wt] = cn;
+        total += cn << (wt - 1);
     }
-    if (bad || total == 0) return -1;
+    if (total == 0) return -1;
     int maxbits = 32 - __clz((int)total);
     if (maxbits > 11) return -1;
     uint32_t rest = (1u << maxbits) - total;
     if (rest & (rest - 1)) return -1;
-    if (lane == 0) L.weights[n] = (uint8_t)(32 - __clz((int)rest));
+    const uint32_t lastw = (uint32_t)(32 - __clz((int)rest));  // the implied weight of the last symbol
+    if (lane == 0) L.weights[n] = (uint8_t)lastw;
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (64 * c + (int)lane == n) w[c] = lastw;
+    cntw[lastw] += 1;
     n++;
+    if (cntw[1] < 2 || (cntw[1] & 1)) return -1;
     WSYNC();
-    int cnt1 = 0;
-    for (int i = 0; i < n; i++) cnt1 += L.weights[i] == 1;
-    if (cnt1 < 2 || (cnt1 & 1)) return -1;
-    uint32_t pos = 0;
-    for (int wt = 1; wt <= maxbits; wt++) {
-        const uint32_t len = 1u << (wt - 1);
-        const uint16_t nbv = (uint16_t)((maxbits + 1 - wt) << 8);
-        for (int s = 0; s < n; s++) {
-            if (L.weights[s] != wt) continue;
-            for (uint32_t k = lane; k < len; k += 64) L.huf[pos + k] = (uint16_t)(s | nbv);
-            pos += len;
+    // table position of a symbol: everything of lower weight, then the symbols of its own weight in symbol order
+    uint32_t basew[12];
+    {
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t wt = 1; wt <= 11; wt++) {
+            basew[wt] = acc;
+            acc += cntw[wt] << (wt - 1);
+        }
+    }
+    uint32_t pos[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t wt = 1; wt <= 11; wt++) {
+        uint32_t before = 0;  // symbols of this weight in lower chunks
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint64_t m = __ballot(w[c] == wt);
+            if (w[c] == wt) pos[c] = basew[wt] + ((before + (uint32_t)__popcll(m & lanemask_lt())) << (wt - 1));
+            before += (uint32_t)__popcll(m);
+        }
+    }
+    // fill: one symbol after the other, the 64 lanes spread over the symbol's 2^(weight-1) entries
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        uint64_t todo = __ballot(w[c] != 0);
+        while (todo) {
+            const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+            todo &= todo - 1;
+            const uint32_t wj = rdlane(w[c], j), pj = rdlane(pos[c], j);
+            const uint32_t len = 1u << (wj - 1);
+            const uint16_t val = (uint16_t)((64u * c + j) | (((uint32_t)maxbits + 1u - wj) << 8));
+            for (uint32_t k = lane; k < len; k += 64) L.huf[pj + k] = val;
         }
     }
     if (lane == 0) {
