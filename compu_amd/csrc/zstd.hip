@@ -590,26 +590,43 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
         if (fse_build(L, view(L.wt), nsym, al)) return -1;
         BackBits s;
         if (!bb_init(b, s, p0 + 1 + (uint32_t)c, hb - (uint32_t)c)) return -1;
-        uint32_t s1 = bb_read(b, s, (uint32_t)al), s2 = bb_read(b, s, (uint32_t)al);
-        if (s.avail < 0) return -1;
+        // the weight stream is at most 127 bytes: lane i keeps its i-th dword, so the (serial, two-state) FSE decode below
+        // reads bits with readlane instead of a memory round trip per symbol
+        const uint32_t d0 = rdfirst(s.lo >> 5), lo0 = rdfirst(s.lo);
+        const uint32_t mydw = d0 + lane_id() < b.total_dw ? b.g32[d0 + lane_id()] : 0u;
+        int32_t avail = (int32_t)rdfirst((uint32_t)s.avail);
+        auto take = [&](uint32_t nbits) -> uint32_t {  // bb_read on the register copy
+            uint32_t v = 0;
+            if (nbits != 0 && avail > 0) {
+                const uint32_t have = (uint32_t)avail >= nbits ? nbits : (uint32_t)avail;
+                const uint32_t pos = lo0 + (uint32_t)avail - have;
+                const uint32_t i = rdfirst((pos >> 5) - d0) & 63u;
+                const uint32_t w0 = rdlane(mydw, i), w1 = rdlane(mydw, (i + 1u) & 63u);
+                v = (__builtin_amdgcn_alignbit(w1, w0, pos & 31u) & ((1u << have) - 1u)) << (nbits - have);
+            }
+            avail -= (int32_t)nbits;
+            return v;
+        };
+        uint32_t s1 = take((uint32_t)al), s2 = take((uint32_t)al);
+        if (avail < 0) return -1;
         const bool w = lane_id() == 0;
         for (;;) {
             if (nw > 253) return -1;
-            uint32_t e1 = L.wt.e[s1];
+            uint32_t e1 = rdfirst(L.wt.e[s1]);
             if (w) L.weights[nw] = (uint8_t)(e1 & 63u);
             nw++;
-            s1 = (e1 >> 16) + bb_read(b, s, (e1 >> 6) & 15u);
-            if (s.avail < 0) {
+            s1 = (e1 >> 16) + take((e1 >> 6) & 15u);
+            if (avail < 0) {
                 if (w) L.weights[nw] = (uint8_t)(L.wt.e[s2] & 63u);
                 nw++;
                 break;
             }
             if (nw > 253) return -1;
-            uint32_t e2 = L.wt.e[s2];
+            uint32_t e2 = rdfirst(L.wt.e[s2]);
             if (w) L.weights[nw] = (uint8_t)(e2 & 63u);
             nw++;
-            s2 = (e2 >> 16) + bb_read(b, s, (e2 >> 6) & 15u);
-            if (s.avail < 0) {
+            s2 = (e2 >> 16) + take((e2 >> 6) & 15u);
+            if (avail < 0) {
                 if (w) L.weights[nw] = (uint8_t)(L.wt.e[s1] & 63u);
                 nw++;
                 break;
