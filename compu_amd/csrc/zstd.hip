@@ -374,19 +374,28 @@ __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, 
     if (n < 1) return -1;
     uint32_t bit = p0 * 8u;
     const uint32_t endbit = (p0 + n) * 8u;
-    int al = (int)(rd32_at(b, bit) & 15u) + 5;
+    // the description is a few dozen bytes: lane i keeps dword i of it, bits are then read with readlane instead of one
+    // memory round trip per symbol (everything here is wave-uniform)
+    const uint32_t d0 = rdfirst(bit >> 5);
+    const uint32_t mydw = d0 + lane_id() < b.total_dw ? b.g32[d0 + lane_id()] : 0u;
+    auto rdw = [&](uint32_t at) -> uint32_t {
+        const uint32_t i = rdfirst((at >> 5) - d0);
+        if (i < 63u) return __builtin_amdgcn_alignbit(rdlane(mydw, i + 1u), rdlane(mydw, i), at & 31u);
+        return rd32_at(b, at);
+    };
+    int al = (int)(rdw(bit) & 15u) + 5;
     bit += 4;
     if (al > max_al) return -1;
     int remaining = (1 << al) + 1, threshold = 1 << al, nbits = al + 1, sym = 0, prev0 = 0;
     while (remaining > 1 && sym <= max_sym) {
         if (prev0) {
             int n0 = sym;
-            while ((rd32_at(b, bit) & 3u) == 3u) {
+            while ((rdw(bit) & 3u) == 3u) {
                 n0 += 3;
                 bit += 2;
                 if (bit > endbit + 7) return -1;
             }
-            n0 += (int)(rd32_at(b, bit) & 3u);
+            n0 += (int)(rdw(bit) & 3u);
             bit += 2;
             if (n0 > max_sym + 1) return -1;
             while (sym < n0) {
@@ -396,7 +405,7 @@ __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, 
             if (sym > max_sym) break;
         }
         int max = (2 * threshold - 1) - remaining, count;
-        uint32_t bits = rd32_at(b, bit);
+        uint32_t bits = rdw(bit);
         if ((int)(bits & (uint32_t)(threshold - 1)) < max) {
             count = (int)(bits & (uint32_t)(threshold - 1));
             bit += (uint32_t)(nbits - 1);
