@@ -124,10 +124,14 @@ __device__ __forceinline__ void sq_fill(ZLds &L, const Bits &b, SeqBits &s)
 {
     WSYNC();
     s.win0 = ((int32_t)(s.lo + (uint32_t)s.avail) >> 5) + 2 - 256;
-    for (int32_t k = (int32_t)lane_id(); k < 256; k += 64) {
-        int32_t i = s.win0 + k;
-        L.seqwin[k] = (i >= 0 && (uint32_t)i < b.total_dw) ? b.g32[i] : 0u;
+    uint32_t v[4];  // all four loads go out before the first LDS store waits for one
+#pragma unroll
+    for (int32_t r = 0; r < 4; r++) {
+        const int32_t i = s.win0 + 64 * r + (int32_t)lane_id();
+        v[r] = (i >= 0 && (uint32_t)i < b.total_dw) ? b.g32[i] : 0u;
     }
+#pragma unroll
+    for (int32_t r = 0; r < 4; r++) L.seqwin[64 * r + (int32_t)lane_id()] = v[r];
     WSYNC();
 }
 
