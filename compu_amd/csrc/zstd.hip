@@ -1120,6 +1120,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     if ((((int32_t)s.lo + s.avail - 64 - 64 * 96) >> 5) < s.win0) sq_fill(L, b, s);
                     uint32_t my_el = 0, my_eo = 0, my_em = 0;
                     int32_t my_top = 0;
+                    __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
                     for (uint32_t j = 0; j < cn; j++) {
                         // the 64 bits below the read position and the three state entries: six LDS reads in flight together
                         const int32_t top = (int32_t)s.lo + s.avail;
@@ -1165,6 +1166,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             my_top = top;
                         }
                     }
+                    __builtin_amdgcn_s_setprio(0);
                     // ---- parallel part: lane j cuts sequence j's extra bits from the window and forms the values
                     uint32_t ov = 4;
                     if (lane < cn && lane < dec_bad) {
