@@ -951,6 +951,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     }
     if (status == ST_RUNNING) win_load(L, w, pos >> 5);
 
+    __builtin_amdgcn_s_setprio(2);
     while (status == ST_RUNNING) {
         if (last) {
             status = CHIP_FINISHED;
@@ -1110,9 +1111,12 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             STAT_ACC(7);
         }
         STAT_ACC(0);
+        __builtin_amdgcn_s_setprio(0);
         decode_block(L, w, pos, end_bit, gout, opos, cap, status, grow, tables == 1 ? (uint32_t)XT_BITS_FIXED : (uint32_t)XT_BITS STAT_ARG);
+        __builtin_amdgcn_s_setprio(2);  // block headers and table builds are short dependent chains: ahead of the other waves' bulk work
         STAT_T0();
     }
+    __builtin_amdgcn_s_setprio(0);
     STAT_ACC(0);
     if (status == CHIP_FINISHED && wrap) {
         // trailer: gzip CRC-32 + ISIZE (little endian), zlib Adler-32 (big endian)
