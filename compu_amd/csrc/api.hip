@@ -42,7 +42,7 @@ struct Meta {
     uint64_t in_off, out_off;
     uint32_t in_len, out_cap, out_len, in_used;
     int32_t status;
-    uint32_t pad;
+    uint32_t resume[3];  // inflate streaming: see BatchArgs::resume
 };
 
 }  // namespace
@@ -122,6 +122,7 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     a.n = (uint32_t)n;
     a.format = format;
     a.stats = nullptr;
+    a.resume = nullptr;
 #ifdef CHIP_STATS
     a.stats = (unsigned long long *)getenv("CHIP_STATS_PTR") ? (unsigned long long *)strtoull(getenv("CHIP_STATS_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -361,6 +362,8 @@ struct chip_decoder {
     int32_t k_status;
     size_t delivered;  // decoded bytes already handed to the caller
     bool done;
+    size_t d_in_len;      // input bytes already on the device (the stream only grows)
+    uint32_t resume[3];   // inflate: last block boundary the kernel reached (BatchArgs::resume); zeros = from the start
 };
 
 namespace {
@@ -379,33 +382,45 @@ bool dec_reserve_in(chip_decoder *d, size_t need)
     return true;
 }
 
-// decode everything accumulated so far; grows the device output until it is not the limit
+// Decode what has accumulated.  Input is appended to the device copy (only the new bytes cross the link), an inflate
+// stream continues from the last block boundary an earlier call reached (the output so far stays on the device: it is the
+// window and what the trailer checksum covers), so feeding a long stream in pieces costs O(stream), not O(stream^2).
+// zstd frames are decoded from their start each time.  The device output grows (contents kept) while it is the limit.
 bool dec_run(chip_decoder *d)
 {
     if (hipSetDevice(d->device) != hipSuccess) return false;
-    size_t in_len = d->h_in_len;
-    size_t need_in = (in_len + 3) & ~(size_t)3;
-    if (need_in + 16 > d->d_in_cap) {
-        chip_device_free(d->d_in);
-        d->d_in_cap = need_in * 2 + 4096;
-        d->d_in = (uint8_t *)chip_device_alloc(d->d_in_cap);
-        if (!d->d_in) return false;
+    const size_t in_len = d->h_in_len;
+    const size_t need_in = ((in_len + 3) & ~(size_t)3) + 16;
+    if (need_in > d->d_in_cap) {
+        const size_t ncap = need_in * 2 + 4096;
+        uint8_t *p = (uint8_t *)chip_device_alloc(ncap);
+        if (!p) return false;
+        chip_device_free(d->d_in);  // (stream-ordered work on it is complete: every call ends with a synchronise)
+        d->d_in = p;
+        d->d_in_cap = ncap;
+        d->d_in_len = 0;  // upload again from the pinned copy
     }
-    if (in_len && hipMemcpyAsync(d->d_in, d->h_in, in_len, hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
+    if (in_len > d->d_in_len) {
+        const size_t from = d->d_in_len & ~(size_t)3;  // keep the copies dword aligned
+        if (hipMemcpyAsync(d->d_in + from, d->h_in + from, in_len - from, hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
+        d->d_in_len = in_len;
+    }
+    const bool inflate = d->format != CHIP_FMT_ZSTD;
     size_t cap = d->d_out_cap;
     if (cap == 0) cap = in_len * 4 > 65536 ? in_len * 4 : 65536;
     for (;;) {
         if (cap > 0xffffffffull) cap = 0xffffffffull;
         if (cap > d->d_out_cap) {
+            uint8_t *p = (uint8_t *)chip_device_alloc(cap);
+            if (!p) return false;
+            const size_t keep = inflate ? (size_t)d->resume[1] : 0;  // an inflate stream resumes: its output so far must survive
+            if (keep && hipMemcpyAsync(p, d->d_out, keep, hipMemcpyDeviceToDevice, d->stream) != hipSuccess) return false;
+            if (keep && hipStreamSynchronize(d->stream) != hipSuccess) return false;
             chip_device_free(d->d_out);
-            d->d_out = (uint8_t *)chip_device_alloc(cap);
-            if (!d->d_out) {
-                d->d_out_cap = 0;
-                return false;
-            }
+            d->d_out = p;
             d->d_out_cap = cap;
         }
-        Meta m = {0, 0, (uint32_t)in_len, (uint32_t)d->d_out_cap, 0, 0, 0, 0};
+        Meta m = {0, 0, (uint32_t)in_len, (uint32_t)d->d_out_cap, 0, 0, 0, {d->resume[0], d->resume[1], d->resume[2]}};
         *d->h_meta = m;
         if (hipMemcpyAsync(d->d_meta, d->h_meta, sizeof(Meta), hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
         BatchArgs a;
@@ -421,10 +436,13 @@ bool dec_run(chip_decoder *d)
         a.n = 1;
         a.format = d->format;
         a.stats = nullptr;
-        hipError_t e = d->format == CHIP_FMT_ZSTD ? launch_zstd_decode(a, d->window_log_max, d->stream) : launch_inflate(a, d->stream);
+        a.resume = inflate ? d->d_meta->resume : nullptr;
+        hipError_t e = inflate ? launch_inflate(a, d->stream) : launch_zstd_decode(a, d->window_log_max, d->stream);
         if (e != hipSuccess) return false;
         if (hipMemcpyAsync(d->h_meta, d->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;
         if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
+        if (inflate)
+            for (int k = 0; k < 3; k++) d->resume[k] = d->h_meta->resume[k];
         if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < 0xffffffffull) {
             cap = d->d_out_cap * 2;
             continue;
@@ -446,6 +464,8 @@ void dec_clear(chip_decoder *d)
     d->k_status = CHIP_NEED_INPUT;
     d->delivered = 0;
     d->done = false;
+    d->d_in_len = 0;
+    d->resume[0] = d->resume[1] = d->resume[2] = 0;
 }
 
 }  // namespace
@@ -605,6 +625,7 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
     a.n = (uint32_t)n;
     a.format = format;
     a.stats = nullptr;
+    a.resume = nullptr;
     hipError_t e = launch_deflate_l1(a, level, 7u, format == CHIP_FMT_ZLIB ? 1u : 0u, 0, nullptr, (hipStream_t)stream);
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
@@ -697,6 +718,7 @@ bool enc_segment(chip_encoder *e, bool final)
     a.n = 1;
     a.format = e->mode;
     a.stats = nullptr;
+    a.resume = nullptr;
     const uint32_t flags = (e->started ? 0u : 1u) | (final ? 2u | 4u : 0u);
     if (launch_deflate_l1(a, e->level, flags, e->check, e->total_in, &e->d_meta->check, e->stream) != hipSuccess) return false;
     if (hipMemcpyAsync(e->h_meta, e->d_meta, sizeof m, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return false;

@@ -37,6 +37,10 @@ struct BatchArgs {
     uint32_t n;
     int32_t format;
     unsigned long long *stats;  // diagnostic builds only (-DCHIP_STATS): 16 words per unit, else nullptr
+    // inflate, streaming decoder only (else nullptr): three words per unit, in and out -- bit offset of the last
+    // block boundary reached (0 = start from the beginning), output bytes produced up to there, wrapper kind.
+    // A later call over the same (longer) input and the same output buffer continues from that boundary.
+    uint32_t *resume;
 };
 
 // launchers (each only enqueues on `stream`)

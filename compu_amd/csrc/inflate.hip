@@ -944,7 +944,20 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             return;
         }
     }
-    if (format != CHIP_FMT_DEFLATE) {
+    uint32_t ck_bit = 0, ck_opos = 0;  // last block boundary reached (streaming decoder: where the next call resumes)
+    bool resumed = false;
+    if (a.resume) {
+        const uint32_t r0 = a.resume[3u * u], r1 = a.resume[3u * u + 1], r2 = a.resume[3u * u + 2];
+        if (r0 != 0 && r0 <= in_len * 8u && r1 <= cap) {
+            resumed = true;
+            pos = start_bit + r0;
+            opos = r1;
+            wrap = r2 & 3u;
+            ck_bit = r0;
+            ck_opos = r1;
+        }
+    }
+    if (!resumed && format != CHIP_FMT_DEFLATE) {
         uint32_t hdr = 0;
         status = parse_wrapper(L.lit_lut, gin, in_len, format, wrap, hdr);
         pos += hdr * 8u;
@@ -957,6 +970,8 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             status = CHIP_FINISHED;
             break;
         }
+        ck_bit = pos - start_bit;
+        ck_opos = opos;
         win_ensure(L, w, pos);
         if (pos + 3 > end_bit) {
             status = CHIP_NEED_INPUT;
@@ -1147,6 +1162,12 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     if (a.stats && lane == 0)
         for (int k = 0; k < 24; k++) a.stats[(size_t)u * 24 + k] = st_[k];
 #endif
+    if (a.resume && lane == 0) {
+        const bool cont = status == CHIP_NEED_INPUT || status == CHIP_NEED_OUTPUT;
+        a.resume[3u * u] = cont ? ck_bit : 0u;
+        a.resume[3u * u + 1] = cont ? ck_opos : 0u;
+        a.resume[3u * u + 2] = wrap;
+    }
     if (lane == 0) {
         uint32_t used = (pos - start_bit + 7u) >> 3;
         if (used > in_len) used = in_len;

@@ -203,3 +203,67 @@ def test_wrapped_units_batch_match_oracle(gpu, alice):
     dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Zlib)
     r = dec.decode(comp, bytearray(100))
     assert not r.is_ok() and r.status.as_raw() == 2 and dec.describe_error(r.status) == "need dictionary"
+
+
+def test_streaming_a_long_gzip_in_small_pieces_is_linear(gpu, alice):
+    """A long stream fed 8 KiB at a time: every call continues from the last block boundary reached (the kernel's
+    resume state) instead of decoding the stream again from its start -- a thousand calls stay cheap -- and the
+    result is the same as in one piece, including the gzip trailer check at the end."""
+    import random
+    import time
+    import zlib
+
+    import compu_amd as compu
+
+    rnd = random.Random(8)
+    big = bytearray()
+    while len(big) < 8_000_000:
+        k = rnd.randrange(4)
+        if k == 0:
+            big += alice[rnd.randrange(len(alice) // 2) :][: rnd.randrange(1, 100000)]
+        elif k == 1:
+            big += rnd.randbytes(rnd.randrange(1, 30000))
+        elif k == 2:
+            big += bytes([rnd.randrange(256)]) * rnd.randrange(1, 50000)
+        else:
+            big += big[-rnd.randrange(1, min(len(big), 32768) + 1) :][: rnd.randrange(1, 3000)] if big else b"x"
+    big = bytes(big)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    comp = co.compress(big) + co.flush()
+    dec = compu.decoder_interface.zlib_hip(compu.ZlibMode.Gzip)
+    out = bytearray()
+    buf = bytearray(1 << 20)
+    t0 = time.perf_counter()
+    pos = 0
+    calls = 0
+    while True:
+        chunk = comp[pos : pos + 8192]
+        r = dec.decode(chunk, buf)
+        calls += 1
+        assert r.is_ok()
+        out += buf[: len(buf) - r.output_remain]
+        pos += len(chunk) - r.input_remain
+        if r.status == compu.DecodeStatus.Finished:
+            break
+        if r.status == compu.DecodeStatus.NeedInput:
+            assert pos < len(comp)
+    dt = time.perf_counter() - t0
+    assert bytes(out) == big and pos == len(comp)
+    assert calls >= len(comp) // 8192
+    assert dt < 60, f"{calls} calls took {dt:.1f} s: the stream is being decoded from its start again"
+    # a corrupted trailer is still caught when the stream arrives in pieces
+    dec.reset()
+    bad = bytearray(comp)
+    bad[-6] ^= 0x10
+    pos = 0
+    status = None
+    while pos < len(bad):
+        r = dec.decode(bytes(bad[pos : pos + 65536]), buf)
+        if not r.is_ok():
+            status = r.status
+            break
+        pos += min(65536, len(bad) - pos) - r.input_remain
+        if r.status == compu.DecodeStatus.Finished:
+            status = r.status
+            break
+    assert status == compu.DecodeError(-3)
