@@ -24,6 +24,7 @@ from .api import (  # noqa: F401
     ZstdOptions,
     decode_batch,
     decode_batch_host,
+    encode_batch_host,
     trim,
     decoder_interface,
     detect_batch,

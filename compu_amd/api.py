@@ -68,6 +68,8 @@ def lib():
     L.chip_stream_sync.argtypes = [vp]
     L.chip_decode_batch_host.restype = C.c_int
     L.chip_decode_batch_host.argtypes = [C.c_int, C.c_size_t] + [vp] * 9 + [C.c_int, C.c_size_t]
+    L.chip_encode_batch_host.restype = C.c_int
+    L.chip_encode_batch_host.argtypes = [C.c_int, C.c_int, C.c_size_t] + [vp] * 8 + [C.c_int, C.c_size_t]
     L.chip_trim.restype = C.c_int
     L.chip_trim.argtypes = []
     L.chip_decoder_new.restype = vp
@@ -594,6 +596,25 @@ def decode_batch_host(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, de
     if rc != 0:
         raise RuntimeError(f"chip_decode_batch_host failed: {rc}")
     return out_len, in_used, status
+
+
+def encode_batch_host(fmt, level, in_buf, in_off, in_len, out_buf, out_off, out_cap, device=-1, slice_bytes=0):
+    """chip_encode_batch_host over numpy arrays in host memory: returns (out_len, status)."""
+    import numpy as np
+
+    n = len(in_len)
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
+    out_len = np.zeros(n, np.uint32)
+    status = np.zeros(n, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = lib().chip_encode_batch_host(int(fmt), int(level), n, p(in_buf), p(in_off), p(in_len), p(out_buf), p(out_off), p(out_cap), p(out_len),
+                                      p(status), int(device), int(slice_bytes))
+    if rc != 0:
+        raise RuntimeError(f"chip_encode_batch_host failed: {rc}")
+    return out_len, status
 
 
 def trim():

@@ -142,13 +142,18 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
 
-// Host-memory variant: slices of consecutive units alternate between two streams (H2D -> kernel -> D2H each).
-int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
-                           void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
-                           uint32_t *in_used, int32_t *status, int device, size_t slice_bytes)
+}  // extern "C"
+
+namespace {
+// Host-memory batches: slices of consecutive units alternate between two streams (H2D -> kernel -> D2H each).
+// `launch` enqueues the device batch call for one slice; in_used may be null (encode has no such result).
+template <class Launch>
+int host_pipeline(size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len, void *out_base,
+                  const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, uint32_t *in_used, int32_t *status,
+                  int device, size_t slice_bytes, Launch launch)
 {
     if (n == 0) return CHIP_OK;
-    if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !in_used || !status)
+    if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !status)
         return CHIP_E_INVALID;
     if (!device_ok()) return CHIP_E_NO_DEVICE;
     if (device >= 0 && hipSetDevice(device) != hipSuccess) return CHIP_E_INVALID;
@@ -194,7 +199,7 @@ int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint
         const size_t m = ln.i1 - ln.i0;
         const uint32_t *r = (const uint32_t *)(ln.h_arr + m * 24);
         memcpy(out_len + ln.i0, r, m * 4);
-        memcpy(in_used + ln.i0, r + m, m * 4);
+        if (in_used) memcpy(in_used + ln.i0, r + m, m * 4);
         memcpy(status + ln.i0, r + 2 * m, m * 4);
         ln.i1 = ln.i0;
         return true;
@@ -242,8 +247,7 @@ int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint
         uint32_t *d_in_len = (uint32_t *)(d_out_off + m), *d_out_cap = d_in_len + m, *d_res = d_out_cap + m;
         bool ok = hipMemcpyAsync(ln.d_arr, ln.h_arr, m * 24, hipMemcpyHostToDevice, ln.stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(ln.d_in, (const uint8_t *)in_base + in_base_lo, in_span, hipMemcpyHostToDevice, ln.stream) == hipSuccess;
-        ok = ok && chip_decode_batch(format, m, ln.d_in, d_in_off, d_in_len, ln.d_out, d_out_off, d_out_cap, d_res, d_res + m,
-                                     (int32_t *)(d_res + 2 * m), ln.stream) == CHIP_OK;
+        ok = ok && launch(m, ln.d_in, d_in_off, d_in_len, ln.d_out, d_out_off, d_out_cap, d_res, d_res + m, (int32_t *)(d_res + 2 * m), ln.stream) == CHIP_OK;
         ok = ok && hipMemcpyAsync((uint8_t *)out_base + o_lo, ln.d_out, out_span, hipMemcpyDeviceToHost, ln.stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(ln.h_arr + m * 24, d_res, m * 12, hipMemcpyDeviceToHost, ln.stream) == hipSuccess;
         if (!ok) {
@@ -276,6 +280,32 @@ int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint
         chip_pinned_free(ln.h_arr);
     }
     return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                           uint32_t *in_used, int32_t *status, int device, size_t slice_bytes)
+{
+    if (!in_used) return CHIP_E_INVALID;
+    return host_pipeline(n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, in_used, status, device, slice_bytes,
+                         [=](size_t m, const void *di, const uint64_t *dio, const uint32_t *dil, void *dout, const uint64_t *doo,
+                             const uint32_t *doc, uint32_t *dol, uint32_t *diu, int32_t *dst, void *st) {
+                             return chip_decode_batch(format, m, di, dio, dil, dout, doo, doc, dol, diu, dst, st);
+                         });
+}
+
+int chip_encode_batch_host(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
+                           int device, size_t slice_bytes)
+{
+    return host_pipeline(n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, nullptr, status, device, slice_bytes,
+                         [=](size_t m, const void *di, const uint64_t *dio, const uint32_t *dil, void *dout, const uint64_t *doo,
+                             const uint32_t *doc, uint32_t *dol, uint32_t *, int32_t *dst, void *st) {
+                             return chip_encode_batch(format, level, m, di, dio, dil, dout, doo, doc, dol, dst, st);
+                         });
 }
 
 // Detection::detect, src/decoder/mod.rs:28-114 (including the fall-through of the 0x68 arm,

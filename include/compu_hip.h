@@ -199,6 +199,12 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
 /* Worst-case compressed size for in_len input bytes in `format` (sizing out_cap). */
 size_t chip_encode_bound(int format, size_t in_len);
 
+/* chip_encode_batch for data in (pinned) host memory: same two-stream slicing as chip_decode_batch_host; the host
+ * output range of a slice is written as a whole (bytes between out_len[i] and out_cap[i] end up unspecified). */
+int chip_encode_batch_host(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                           void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
+                           int device, size_t slice_bytes);
+
 #ifdef __cplusplus
 }
 #endif

@@ -180,3 +180,45 @@ def test_level1_ratio_against_zlib(gpu, alice):
         assert zlib.decompress(bytes(vec), -15) == data
         assert len(vec) <= 1.5 * len(zlib.compress(data, 1))
         enc.reset()
+
+
+def test_host_memory_encode_matches_the_oracle(gpu):
+    """chip_encode_batch_host (units in host memory, sliced over two streams): the same bytes as the oracle encoder."""
+    import random
+    import zlib
+
+    import numpy as np
+
+    import compu_amd
+    from oracle import oracle as O
+
+    rnd = random.Random(21)
+    alice = golden("alice29.txt")
+    datas = []
+    for it in range(120):
+        n = rnd.choice([0, 1, 100, 4000, 65536, 90000])
+        k = rnd.randrange(3)
+        if k == 0:
+            s0 = rnd.randrange(0, max(1, len(alice) - n))
+            datas.append(alice[s0 : s0 + n])
+        elif k == 1:
+            datas.append(rnd.randbytes(n))
+        else:
+            datas.append(bytes(rnd.choice(b"abcd") for _ in range(n)))
+    lens = np.array([len(d) for d in datas], np.uint32)
+    offs = np.zeros(len(datas), np.uint64)
+    offs[1:] = np.cumsum(lens[:-1].astype(np.uint64))
+    buf = np.zeros(int(lens.astype(np.uint64).sum()) + 8, np.uint8)
+    buf[: int(lens.astype(np.uint64).sum())] = np.frombuffer(b"".join(datas), np.uint8)
+    caps = np.array([compu_amd.encode_bound(31, len(d)) for d in datas], np.uint32)
+    ooff = np.zeros(len(datas), np.uint64)
+    ooff[1:] = np.cumsum((caps[:-1].astype(np.uint64) + 15) & ~np.uint64(15))
+    out = np.zeros(int(ooff[-1] + caps[-1]) + 16, np.uint8)
+    ol, st = compu_amd.encode_batch_host(31, 1, buf, offs, lens, out, ooff, caps, slice_bytes=1 << 19)
+    for i, d in enumerate(datas):
+        got = bytes(out[int(ooff[i]) : int(ooff[i]) + int(ol[i])])
+        assert st[i] == 2, (i, st[i])
+        assert zlib.decompress(got, 31) == d, i
+        enc = O.DeflateEncoder(O.MODE_GZIP, 1)
+        ref, in_rem, out_rem, est = enc.encode(d, int(caps[i]), O.OP_FINISH)
+        assert got == ref, i
