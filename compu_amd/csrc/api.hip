@@ -394,6 +394,7 @@ struct chip_decoder {
     bool done;
     size_t d_in_len;      // input bytes already on the device (the stream only grows)
     uint32_t resume[3];   // inflate: last block boundary the kernel reached (BatchArgs::resume); zeros = from the start
+    uint32_t *d_zres;     // zstd: device blob with the kernel's block checkpoint (header + decode tables), see zstd.hip
 };
 
 namespace {
@@ -436,6 +437,11 @@ bool dec_run(chip_decoder *d)
         d->d_in_len = in_len;
     }
     const bool inflate = d->format != CHIP_FMT_ZSTD;
+    constexpr size_t ZRES_BYTES = (16 + 2312) * 4 + 64;  // zstd.hip: ZRES_HDR + ZSAVE_WORDS
+    if (!inflate && !d->d_zres) {
+        d->d_zres = (uint32_t *)chip_device_alloc(ZRES_BYTES);
+        if (!d->d_zres || hipMemsetAsync(d->d_zres, 0, 64, d->stream) != hipSuccess) return false;
+    }
     size_t cap = d->d_out_cap;
     if (cap == 0) cap = in_len * 4 > 65536 ? in_len * 4 : 65536;
     for (;;) {
@@ -443,7 +449,7 @@ bool dec_run(chip_decoder *d)
         if (cap > d->d_out_cap) {
             uint8_t *p = (uint8_t *)chip_device_alloc(cap);
             if (!p) return false;
-            const size_t keep = inflate ? (size_t)d->resume[1] : 0;  // an inflate stream resumes: its output so far must survive
+            const size_t keep = inflate ? (size_t)d->resume[1] : (size_t)d->k_out_len;  // a stream resumes: its output so far must survive
             if (keep && hipMemcpyAsync(p, d->d_out, keep, hipMemcpyDeviceToDevice, d->stream) != hipSuccess) return false;
             if (keep && hipStreamSynchronize(d->stream) != hipSuccess) return false;
             chip_device_free(d->d_out);
@@ -466,13 +472,14 @@ bool dec_run(chip_decoder *d)
         a.n = 1;
         a.format = d->format;
         a.stats = nullptr;
-        a.resume = inflate ? d->d_meta->resume : nullptr;
+        a.resume = inflate ? d->d_meta->resume : d->d_zres;
         hipError_t e = inflate ? launch_inflate(a, d->stream) : launch_zstd_decode(a, d->window_log_max, d->stream);
         if (e != hipSuccess) return false;
         if (hipMemcpyAsync(d->h_meta, d->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;
         if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
         if (inflate)
             for (int k = 0; k < 3; k++) d->resume[k] = d->h_meta->resume[k];
+        d->k_out_len = d->h_meta->out_len;
         if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < 0xffffffffull) {
             cap = d->d_out_cap * 2;
             continue;
@@ -496,6 +503,10 @@ void dec_clear(chip_decoder *d)
     d->done = false;
     d->d_in_len = 0;
     d->resume[0] = d->resume[1] = d->resume[2] = 0;
+    if (d->d_zres) {  // the next stream starts from its frame header
+        (void)hipMemsetAsync(d->d_zres, 0, 64, d->stream);
+        (void)hipStreamSynchronize(d->stream);
+    }
 }
 
 }  // namespace
@@ -611,12 +622,16 @@ void chip_decoder_free(chip_decoder *d)
 {
     if (!d) return;
     (void)hipSetDevice(d->device);
-    if (d->stream) (void)hipStreamDestroy(d->stream);
+    if (d->stream) {
+        chip::release_inflate_scratch_of(d->stream);  // the stream's token scratch goes with it
+        (void)hipStreamDestroy(d->stream);
+    }
     chip_pinned_free(d->h_in);
     chip_pinned_free(d->h_meta);
     chip_device_free(d->d_in);
     chip_device_free(d->d_out);
     chip_device_free(d->d_meta);
+    chip_device_free(d->d_zres);
     host_free(d);
 }
 

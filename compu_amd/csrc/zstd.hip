@@ -11,6 +11,8 @@
 // the END of the unit's output capacity (they are always consumed before the output cursor reaches
 // them, as in libzstd's in-destination literal buffer); raw literals are read in place from the
 // input; the match window is the output itself.
+#include <cstddef>
+
 #include "chip_internal.h"
 
 namespace chip {
@@ -61,6 +63,14 @@ struct alignas(16) ZLds {
     uint32_t xheads[64];   // copy phase: owner of every byte of a 256-byte step
     uint32_t xpar[192];    // copy phase: per-item parameters
 };
+
+// Streaming decoder only (BatchArgs::resume, one unit): checkpoint written after every completed block -- 16 header words
+// ([0] 1 + input bytes consumed (0 = none), [1] output bytes, [2..4] repeat offsets, [5] flags: 1 checksum, 2 content size
+// known, 4 all blocks done, [6,7] content size, [8,9] window, [10,11] output limit) followed by the LDS image of the
+// Huffman and FSE tables, which later blocks may reuse (treeless literals, repeat modes).
+constexpr uint32_t ZSAVE_WORDS = 2312;  // ZLds up to `weights`
+constexpr uint32_t ZRES_HDR = 16;
+static_assert(offsetof(ZLds, weights) == ZSAVE_WORDS * 4, "checkpoint covers the decode tables");
 
 // the unit's input seen as dwords (aligned down), addressed by absolute bit index
 struct Bits {
@@ -785,8 +795,46 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
 #define ZFAIL(code) do { status = -(code); goto done; } while (0)
 #define ZNEED_INPUT() do { status = CHIP_NEED_INPUT; goto done; } while (0)
 
+    uint32_t *const rs = a.resume;  // streaming decoder: checkpoint blob of this (single) unit, else nullptr
+    bool resumed = false, blocks_done = false;
+    if (rs && rs[0] != 0 && rs[0] - 1u <= in_len && rs[1] <= cap) {
+        resumed = true;
+        ip = B0 + rs[0] - 1u;
+        opos = rs[1];
+        rep0 = rs[2];
+        rep1 = rs[3];
+        rep2 = rs[4];
+        has_checksum = rs[5] & 1u;
+        has_fcs = (rs[5] >> 1) & 1u;
+        blocks_done = (rs[5] >> 2) & 1u;
+        fcs = rs[6] | ((uint64_t)rs[7] << 32);
+        window = rs[8] | ((uint64_t)rs[9] << 32);
+        out_limit = rs[10] | ((uint64_t)rs[11] << 32);
+        for (uint32_t k = lane; k < ZSAVE_WORDS; k += 64) ((uint32_t *)&L)[k] = rs[ZRES_HDR + k];
+        WSYNC();
+    }
+    auto save_checkpoint = [&](bool all_done) {
+        if (!rs) return;
+        WSYNC();
+        for (uint32_t k = lane; k < ZSAVE_WORDS; k += 64) rs[ZRES_HDR + k] = ((const uint32_t *)&L)[k];
+        if (lane == 0) {
+            rs[1] = opos;
+            rs[2] = rep0;
+            rs[3] = rep1;
+            rs[4] = rep2;
+            rs[5] = (has_checksum ? 1u : 0u) | (has_fcs ? 2u : 0u) | (all_done ? 4u : 0u);
+            rs[6] = (uint32_t)fcs;
+            rs[7] = (uint32_t)(fcs >> 32);
+            rs[8] = (uint32_t)window;
+            rs[9] = (uint32_t)(window >> 32);
+            rs[10] = (uint32_t)out_limit;
+            rs[11] = (uint32_t)(out_limit >> 32);
+            rs[0] = 1u + (ip - B0);
+        }
+    };
+
     // ---- frame header (sec. 3.1.1.1) ------------------------------------------------------------
-    {
+    if (!resumed) {
         if (END - ip < 4) ZNEED_INPUT();
         uint32_t magic = rd32_at(b, ip * 8u);
         if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {  // skippable frame (sec. 3.1.2): a frame without content
@@ -829,7 +877,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
     }
 
     // ---- blocks (sec. 3.1.1.2) --------------------------------------------------------------------
-    for (;;) {
+    while (!blocks_done) {
         if (END - ip < 3) ZNEED_INPUT();
         const uint32_t bh = rd32_at(b, ip * 8u) & 0xffffffu;
         const uint32_t last = bh & 1u, type = (bh >> 1) & 3u, bsz = bh >> 3;
@@ -1379,8 +1427,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         }
         if (last) {
             if (has_fcs && (uint64_t)opos != fcs) ZFAIL(ZSTD_E_CORRUPTION);
-            break;
+            blocks_done = true;
         }
+        save_checkpoint(blocks_done);
     }
     if (has_checksum) {
         if (END - ip < 4) ZNEED_INPUT();
@@ -1392,6 +1441,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
     }
     status = CHIP_FINISHED;
 done:
+    if (rs && lane == 0 && status != CHIP_NEED_INPUT && status != CHIP_NEED_OUTPUT) rs[0] = 0;  // nothing to continue
     if (lane == 0) {
         a.out_len[u] = opos;
         a.in_used[u] = status == CHIP_NEED_INPUT ? in_len : ip - B0;

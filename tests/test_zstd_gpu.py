@@ -186,3 +186,53 @@ def test_large_multiblock_frames(gpu, alice):
         comp = zstd_ref.compress(z, big, level, True, True)
         outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, [comp], [len(big)], check_tail=False)
         assert st[0] == 2 and iu[0] == len(comp) and outs[0] == big, (level, st[0], ol[0])
+
+
+def test_streaming_a_long_zstd_frame_in_small_pieces_is_linear(gpu, alice):
+    """A multi-block frame fed 16 KiB at a time: every call continues from the last completed block (the kernel's
+    checkpoint: cursor, repeat offsets, decode tables) instead of decoding the frame again from its header."""
+    import time
+
+    import compu_amd as compu
+
+    z = zstd_ref.load()
+    rnd = random.Random(31)
+    big = bytearray()
+    while len(big) < 6_000_000:
+        k = rnd.randrange(4)
+        if k == 0:
+            big += alice[rnd.randrange(len(alice) // 2) :][: rnd.randrange(1, 100000)]
+        elif k == 1:
+            big += rnd.randbytes(rnd.randrange(1, 30000))
+        elif k == 2:
+            big += bytes([rnd.randrange(256)]) * rnd.randrange(1, 50000)
+        else:
+            big += big[-rnd.randrange(1, min(len(big), 100000) + 1) :][: rnd.randrange(1, 3000)] if big else b"x"
+    big = bytes(big)
+    comp = zstd_ref.compress(z, big, 3, True, True)
+    dec = compu.decoder_interface.zstd_hip()
+    out = bytearray()
+    buf = bytearray(1 << 20)
+    t0 = time.perf_counter()
+    pos = 0
+    calls = 0
+    while True:
+        chunk = comp[pos : pos + 16384]
+        r = dec.decode(chunk, buf)
+        calls += 1
+        assert r.is_ok(), r.status
+        out += buf[: len(buf) - r.output_remain]
+        pos += len(chunk) - r.input_remain
+        if r.status == compu.DecodeStatus.Finished:
+            break
+        if r.status == compu.DecodeStatus.NeedInput:
+            assert pos < len(comp)
+    dt = time.perf_counter() - t0
+    assert bytes(out) == big and pos == len(comp)
+    assert dt < 60, f"{calls} calls took {dt:.1f} s: the frame is being decoded from its start again"
+    # the same decoder, reset, decodes another frame from its header
+    dec.reset()
+    small = zstd_ref.compress(z, alice[:5000], 3, True, True)
+    o2 = bytearray(6000)
+    r = dec.decode(small, o2)
+    assert r.status == compu.DecodeStatus.Finished and bytes(o2[: len(o2) - r.output_remain]) == alice[:5000]

@@ -79,4 +79,47 @@ for it in range(n_streams):
         bad += 1
         print("MISMATCH", it, wb, n, len(comp), kind, piece, len(obuf), repr(status), want, len(out), len(ref_out), flush=True)
     if it % 20 == 19: print(f"{it + 1} streams, {bad} mismatches", flush=True)
-print("DONE", n_streams, bad)
+# ---- zstd frames through the streaming decoder
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import zstd_ref
+Z = zstd_ref.load()
+zbad = 0
+nz = max(1, n_streams // 3)
+for it in range(nz):
+    n = rnd.choice([0, 7, 3000, 70000, 400000, 1500000])
+    data = mk(n)
+    comp = bytearray(zstd_ref.compress(Z, data, rnd.choice([1, 3, 9]), rnd.random() < 0.7, rnd.random() < 0.8))
+    kind = rnd.randrange(5)
+    if kind == 0 and comp: comp[rnd.randrange(len(comp))] ^= 1 << rnd.randrange(8)
+    elif kind == 1: comp = comp[:rnd.randrange(len(comp) + 1)]
+    comp = bytes(comp)
+    ref_out, ref_rem, _, ref_st, ref_err = O.ZstdDecoder().decode(comp, n + 70000)
+    dec = compu.decoder_interface.zstd_hip()
+    out = bytearray()
+    pos = 0
+    status = None
+    piece = max(rnd.choice([1, 100, 5000, 70000, 1 << 20]), len(comp) // 1500 + 1)
+    obuf = bytearray(max(rnd.choice([50, 4096, 100000, 1 << 20]), n // 1500 + 1))
+    for guard in range(20000):
+        chunk = comp[pos:pos + rnd.randrange(1, piece + 1)]
+        r = dec.decode(chunk, obuf)
+        out += obuf[:len(obuf) - r.output_remain]
+        if not r.is_ok():
+            status = r.status
+            break
+        pos += len(chunk) - r.input_remain
+        if r.status == compu.DecodeStatus.Finished:
+            status = 2
+            break
+        if pos >= len(comp) and r.output_remain == len(obuf):
+            status = 0
+            break
+    want = ref_err if ref_err else ref_st
+    if want == 2 or want == 0:
+        ok = bytes(out) == ref_out and status == want
+    else:  # corrupt: an error, with whatever was produced before it a prefix of the oracle's or vice versa
+        ok = isinstance(status, compu.DecodeError) or status == 0
+    if not ok:
+        zbad += 1
+        print("ZSTD MISMATCH", it, n, len(comp), kind, piece, len(obuf), repr(status), want, len(out), len(ref_out), flush=True)
+print("DONE", n_streams, bad, nz, zbad)
