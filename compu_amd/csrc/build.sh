@@ -4,11 +4,11 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="$here/../libcompu_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function \
+"$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall \
     -o "$out" "$here"/*.hip "$@"
 echo "built $out"
 if [ "${CHIP_BUILD_STATS:-0}" = "1" ]; then
-    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -Wno-unused-function -DCHIP_STATS \
+    "$HIPCC" --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wall -DCHIP_STATS \
         -o "$here/../libcompu_hip_stats.so" "$here"/*.hip
     echo "built $here/../libcompu_hip_stats.so (diagnostic)"
 fi

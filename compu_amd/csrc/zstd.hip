@@ -86,25 +86,11 @@ __device__ __forceinline__ uint32_t rd32_at(const Bits &b, uint32_t bit)
     return __builtin_amdgcn_alignbit(d1, d0, bit & 31u);
 }
 
-// backward bitstream over absolute bit range [lo, pos): peek/read n <= 24 bits, MSB = the bit at pos-1;
-// bits below `lo` read as zero and `over` records that the stream was over-read
+// backward bitstream over the absolute bit range [lo, lo + avail): the readers take bits from the top, MSB first
 struct BackBits {
     uint32_t lo;
     int32_t avail;  // unread bits (negative once over-read)
 };
-
-__device__ __forceinline__ uint32_t bb_peek(const Bits &b, const BackBits &s, uint32_t n)
-{
-    if (n == 0 || s.avail <= 0) return 0;
-    if ((uint32_t)s.avail >= n) return rd32_at(b, s.lo + (uint32_t)s.avail - n) & ((1u << n) - 1u);
-    return (rd32_at(b, s.lo) & ((1u << s.avail) - 1u)) << (n - (uint32_t)s.avail);
-}
-__device__ __forceinline__ uint32_t bb_read(const Bits &b, BackBits &s, uint32_t n)
-{
-    uint32_t v = bb_peek(b, s, n);
-    s.avail -= (int32_t)n;
-    return v;
-}
 
 // stream of `nbytes` bytes starting at absolute byte `byte0`; false if empty or its last byte is zero
 __device__ __forceinline__ bool bb_init(const Bits &b, BackBits &s, uint32_t byte0, uint32_t nbytes)
@@ -618,7 +604,7 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
         const uint32_t d0 = rdfirst(s.lo >> 5), lo0 = rdfirst(s.lo);
         const uint32_t mydw = d0 + lane_id() < b.total_dw ? b.g32[d0 + lane_id()] : 0u;
         int32_t avail = (int32_t)rdfirst((uint32_t)s.avail);
-        auto take = [&](uint32_t nbits) -> uint32_t {  // bb_read on the register copy
+        auto take = [&](uint32_t nbits) -> uint32_t {  // next nbits (<= 24) of the stream; bits below its start read as zero
             uint32_t v = 0;
             if (nbits != 0 && avail > 0) {
                 const uint32_t have = (uint32_t)avail >= nbits ? nbits : (uint32_t)avail;
