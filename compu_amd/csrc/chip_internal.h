@@ -78,6 +78,14 @@ __device__ __forceinline__ uint32_t rdlane(uint32_t v, uint32_t l)
     return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)l);
 }
 __device__ __forceinline__ uint32_t rdfirst(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+// The same for a pointer: tells the compiler that a value every lane holds alike is wave-uniform, so that it lives in
+// scalar registers and loops over it become scalar branches instead of exec-mask loops.
+template <typename T>
+__device__ __forceinline__ T *rdfirst_ptr(T *p)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    return (T *)(uintptr_t)(((uint64_t)rdfirst((uint32_t)(v >> 32)) << 32) | rdfirst((uint32_t)v));
+}
 
 // DPP lane moves within the wave (gfx9 controls): lanes without a source keep 0
 template <int CTRL, int ROW_MASK = 0xf>

@@ -25,6 +25,12 @@
 
 namespace chip {
 
+// phases of a unit's work; experiments: -DCHIP_PHASE_FN='__attribute__((noinline))' (slower: LDS accesses through a
+// WaveLds reference become flat accesses in an out-of-line function)
+#ifndef CHIP_PHASE_FN
+#define CHIP_PHASE_FN
+#endif
+
 // Diagnostic build (-DCHIP_STATS): per-unit cycle and event counters; compiled out of the product.
 #ifdef CHIP_STATS
 #define STAT_DECL unsigned long long st_[24] = {0}; unsigned long long st_t0_ = 0
@@ -43,8 +49,9 @@ struct Stats { unsigned long long *st_; unsigned long long &st_t0_; };
 #define STAT_ARG
 #endif
 // stat slots (cycles): 0 other header work, 1 window load, 2 walk, 3 path resolve, 4 code lengths (+ block header), 5 table
-// build, 6 checksum/trailer, 7 sub-tables, 16 chunk fetch + set-up, 17 copy steps + chunk store, 20 rest of the flush;
-// (counts): 8 super-rounds, 9 lanes on the path, 10 tokens, 11 walk loop trips (4 tokens each), 13 chunks, 14 copy steps
+// build, 6 checksum/trailer, 7 sub-tables, 16 token groups (fetch, placement, literals, match queue), 17 match rounds,
+// 18 chunk store, 20 rest of the flush; (counts): 8 super-rounds, 9 lanes on the path, 10 tokens, 11 walk loop trips
+// (4 tokens each), 12 parallel copy passes, 13 chunks, 14 match rounds, 15 matches copied by the whole wave
 
 // ---- table entry format (shared by lit/len, distance and code-length tables) -------------------
 // [3:0] code length (0 = longer than the root table, resolve canonically)
@@ -188,7 +195,7 @@ __device__ __forceinline__ uint32_t long_lookup(const LongCodes<ROOT> &lc, const
 
 // Build a canonical Huffman decode table from code lengths (RFC 1951 sec. 3.2.2) with zlib's
 // acceptance rules.  Wave-cooperative; lens[] lives in LDS.  Returns 0 or -1 (uniform).
-__device__ int build_table(WaveLds &L, const uint8_t *lens, int n, int type, int root, uint32_t *lut, uint32_t *sorted,
+__device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n, int type, int root, uint32_t *lut, uint32_t *sorted,
                            HuffMeta &H)
 {
     const uint32_t lane = lane_id();
@@ -453,100 +460,220 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 }
 
 // ---- LZ77 execution -----------------------------------------------------------------------------
-// The true token stream of a super-round is executed a chunk at a time.  A chunk is up to CHUNK_TOKENS
-// tokens producing at most CHUNK_BYTES output bytes; its tokens, their output offsets and a bitmap of the
-// output bytes at which a token starts sit in LDS (in the input window and the boundary rows, both dead
-// until the next super-round).  The output is then produced 256 bytes per step, four consecutive bytes
-// per lane: the owner token of a byte is the number of token starts at or before it (bitmap prefix
-// popcount), a literal's byte comes from the token, a match byte is loaded from the output written
-// earlier -- from the chunk's own output, which is assembled in LDS, or from HBM when the source lies
-// below the chunk -- and the finished chunk goes out with coalesced dword stores.
-#ifndef CHIP_CHUNK_GROUPS
-#define CHIP_CHUNK_GROUPS 6
-#define CHIP_CHUNK_BYTES 1536
+// The true token stream of a super-round is executed a chunk at a time.  A chunk is as many tokens as
+// produce at most CHUNK_BYTES of output; the chunk's output is assembled in LDS (the image) and leaves
+// with coalesced dword stores.  Tokens are taken 64 at a time (lane = token): a wave prefix sum of the
+// output lengths places every token, literal lanes drop their byte into the image at once, match lanes
+// append {position, length, distance} to a queue in LDS.  Whenever 64 matches are queued they are
+// executed one per lane: a lane whose source is complete (entirely below the chunk: the unit's earlier
+// output in HBM; or inside the image below the first match of the round) copies up to COPY_LANE_MAX
+// bytes with 16-byte unaligned loads and exact-length unaligned LDS stores; what is left (sources that
+// depend on matches of the same round, self-overlapping, very long or chunk-straddling matches) is done
+// in further passes or, when few, one match at a time by the whole wave.
+#ifndef CHIP_CHUNK_BYTES
+#define CHIP_CHUNK_BYTES 3072
 #endif
-constexpr uint32_t CHUNK_GROUPS = CHIP_CHUNK_GROUPS;
-constexpr uint32_t CHUNK_TOKENS = 64 * CHUNK_GROUPS;
+#ifndef CHIP_COPY_LANE_MAX
+#define CHIP_COPY_LANE_MAX 32
+#endif
 constexpr uint32_t CHUNK_BYTES = CHIP_CHUNK_BYTES;
-constexpr uint32_t CHUNK_LDS_WORDS = CHUNK_TOKENS + CHUNK_TOKENS / 2 + 3 * (CHUNK_BYTES / 32) + 2 + CHUNK_BYTES / 4 + 2;
+constexpr uint32_t COPY_LANE_MAX = CHIP_COPY_LANE_MAX;
+constexpr uint32_t MQ_CAP = 128;  // queued matches: at most 63 left over + 64 new
+constexpr uint32_t IMG_WORDS = CHUNK_BYTES / 4 + 8;  // + room for the 16-byte reads that run past a source's end
+constexpr uint32_t CHUNK_LDS_WORDS = IMG_WORDS + 2 * MQ_CAP;
 static_assert(CHUNK_LDS_WORDS <= IN_DW + ROW_WORDS * 64, "the chunk state lives in the input window and the boundary rows");
-static_assert(CHUNK_BYTES / 32 <= 64, "one wave scan covers the bitmap words");
+static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0, "geometry");
 
 struct ChunkLds {
-    uint32_t *tok;     // [CHUNK_TOKENS]
-    uint16_t *start;   // [CHUNK_TOKENS] output offset of the token, relative to the chunk's dword-aligned base
-    uint32_t *heads;   // [CHUNK_BYTES / 32] bit x set = a token starts at offset x
-    uint32_t *wpre;    // [CHUNK_BYTES / 32] token starts in all lower words
-    uint32_t *dmap;    // [CHUNK_BYTES / 32] bit x set = byte x waits for a source byte of its own step (all clear between steps)
-    uint32_t *pmask;   // [2] gather scratch: piece starts inside a 64-token group
-    uint32_t *out;     // [CHUNK_BYTES / 4 + 2] the chunk's output bytes by offset
+    uint32_t *out;    // [IMG_WORDS] the chunk's output bytes by offset (offset 0 = the dword-aligned address below the chunk)
+    uint32_t *mq_x;   // [MQ_CAP] queued match: offset of its first output byte
+    uint32_t *mq_ld;  // [MQ_CAP] queued match: length | distance << 16
 };
 
 __device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
 {
     static_assert(offsetof(WaveLds, rows) == offsetof(WaveLds, inbuf) + sizeof(uint32_t) * IN_DW, "window and rows are contiguous");
     ChunkLds c;
-    c.tok = L.inbuf;
-    c.start = (uint16_t *)(c.tok + CHUNK_TOKENS);
-    c.heads = c.tok + CHUNK_TOKENS + CHUNK_TOKENS / 2;
-    c.wpre = c.heads + CHUNK_BYTES / 32;
-    c.dmap = c.wpre + CHUNK_BYTES / 32;
-    c.pmask = c.dmap + CHUNK_BYTES / 32;
-    c.out = c.pmask + 2;
+    c.out = L.inbuf;
+    c.mq_x = c.out + IMG_WORDS;
+    c.mq_ld = c.mq_x + MQ_CAP;
     return c;
+}
+
+// unaligned accesses (gfx950 handles any byte alignment for LDS and global dword accesses); LDS pointers carry their
+// address space so that a choice between an LDS and a global source never turns into a flat access
+struct __attribute__((packed)) U32u { uint32_t v; };
+struct __attribute__((packed)) U16u { uint16_t v; };
+struct __attribute__((packed)) U128u { uint32_t x, y, z, w; };
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS uint8_t lds_u8;
+
+// exactly n (1..16) bytes of v to the LDS address d
+__device__ __forceinline__ void lds_put(lds_u8 *d, const U128u &v, uint32_t n)
+{
+    if (n >= 4) ((LDS_AS U32u *)d)->v = v.x;
+    if (n >= 8) ((LDS_AS U32u *)(d + 4))->v = v.y;
+    if (n >= 12) ((LDS_AS U32u *)(d + 8))->v = v.z;
+    if (n >= 16) ((LDS_AS U32u *)(d + 12))->v = v.w;
+    uint32_t w = n < 4 ? v.x : n < 8 ? v.y : n < 12 ? v.z : v.w;
+    lds_u8 *t = d + (n & 12u);
+    if (n < 16 && (n & 2u)) {
+        ((LDS_AS U16u *)t)->v = (uint16_t)w;
+        w >>= 16;
+        t += 2;
+    }
+    if (n < 16 && (n & 1u)) *t = (uint8_t)w;
+}
+
+// One queued match, copied by the whole wave (any distance, any length, source anywhere below it).
+__device__ __forceinline__ void copy_one_match(lds_u8 *img, const uint8_t *base, uint32_t mis, uint32_t x, uint32_t len, uint32_t dist)
+{
+    const uint32_t lane = lane_id();
+    const int32_t sx = (int32_t)x - (int32_t)dist;
+    for (uint32_t i = lane; i < len; i += 64) {
+        // a self-overlapping match repeats its first `dist` bytes; all of them lie below x and are complete
+        const int32_t s = sx + (int32_t)(dist >= len ? i : small_mod(i, dist));
+        uint8_t b = 0;
+        if (s < (int32_t)mis) b = base[s];
+        if (s >= (int32_t)mis) b = img[s];
+        img[x + i] = b;
+    }
+    LSYNC();
+}
+
+// A round = up to 64 queued matches, one per lane.  round_issue() takes them off the queue and starts the loads of the
+// sources that lie entirely below the chunk (final bytes in HBM: nothing in the chunk can change them); round_finish()
+// copies.  The caller puts the next token group's work between the two, so the loads' latency is covered.
+struct Round {
+    uint32_t x, len, dist;  // first output offset, length (0 = no match in this lane), distance
+    bool glob;              // source entirely below the chunk: v0 / v1 hold its first 32 bytes
+    U128u v0, v1;
+};
+
+// glob_ok: 16-byte reads that start below the chunk may run up to 15 bytes into the chunk's (not yet written) output
+// range without leaving the unit's capacity.
+__device__ __forceinline__ void round_issue(Round &r, const ChunkLds &C, const uint8_t *base, uint32_t mis, uint32_t qh, uint32_t nr,
+                                            bool glob_ok)
+{
+    const uint32_t lane = lane_id();
+    const bool act = lane < nr;
+    const uint32_t qi = (qh + lane) & (MQ_CAP - 1u);
+    r.x = act ? C.mq_x[qi] : 0u;
+    const uint32_t ld = act ? C.mq_ld[qi] : 0u;
+    r.len = ld & 0xffffu;
+    r.dist = ld >> 16;
+    const int32_t sx = (int32_t)r.x - (int32_t)r.dist;
+    r.glob = glob_ok && r.len != 0 && r.len <= COPY_LANE_MAX && sx + (int32_t)r.len <= (int32_t)mis;
+    r.v0 = U128u{0, 0, 0, 0};
+    r.v1 = U128u{0, 0, 0, 0};
+    if (r.glob) r.v0 = *(const U128u *)(base + sx);
+    if (r.glob && r.len > 16u) r.v1 = *(const U128u *)(base + sx + 16);
+}
+
+__device__ __forceinline__ void round_finish(const Round &r, const ChunkLds &C, const uint8_t *base, uint32_t mis STAT_PARAM)
+{
+    const uint32_t lane = lane_id();
+    lds_u8 *const img = (lds_u8 *)C.out;
+    const int32_t sx = (int32_t)r.x - (int32_t)r.dist;
+    uint64_t pend = __ballot(r.len != 0);
+    STAT_ADD(14, 1);
+    while (pend) {
+        const uint32_t f = (uint32_t)__ffsll((long long)pend) - 1u;
+        const uint32_t wp = rdlane(r.x, f);  // every byte below the first pending match is final
+        const bool mine = (pend >> lane) & 1ull;
+        const bool loc = sx >= (int32_t)mis && (uint32_t)sx + r.len <= wp;
+        const bool ready = mine && r.len <= COPY_LANE_MAX && (r.glob || loc);
+        const uint64_t rm = __ballot(ready);
+        if (!((rm >> f) & 1ull)) {  // long, self-overlapping or chunk-straddling: by the whole wave
+            STAT_ADD(15, 1);
+            copy_one_match(img, base, mis, wp, rdlane(r.len, f), rdlane(r.dist, f));
+            pend &= pend - 1ull;
+            continue;
+        }
+        STAT_ADD(12, 1);
+        uint32_t rem = ready ? r.len : 0u;
+#pragma unroll
+        for (uint32_t it = 0; it < COPY_LANE_MAX / 16; it++) {
+            if (it && !__any(rem != 0)) break;
+            U128u v = it ? r.v1 : r.v0;
+            if (rem && !r.glob) {
+                const lds_u8 *sp = img + sx + (int32_t)(16u * it);
+                v.x = ((const LDS_AS U32u *)sp)->v;
+                v.y = ((const LDS_AS U32u *)(sp + 4))->v;
+                v.z = ((const LDS_AS U32u *)(sp + 8))->v;
+                v.w = ((const LDS_AS U32u *)(sp + 12))->v;
+            }
+            if (rem) {
+                const uint32_t n = rem < 16u ? rem : 16u;
+                lds_put(img + r.x + 16u * it, v, n);
+                rem -= n;
+            }
+        }
+        LSYNC();
+        pend &= ~rm;
+    }
 }
 
 // Executes the ntok tokens of the true stream (npieces pieces described by L.pk) into gout at opos.
 // Returns false when decoding must stop (error / output full).
-__device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, uint32_t npieces, uint8_t *gout, uint32_t &opos,
-                             uint32_t cap, int32_t &status STAT_PARAM)
+__device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, uint32_t ntok_, uint32_t npieces_, uint8_t *gout_, uint32_t &opos_,
+                             uint32_t cap_, int32_t &status STAT_PARAM)
 {
     const uint32_t lane = lane_id();
+    // every argument is wave-uniform; say so (scalar registers, scalar loop branches)
+    const uint32_t *const grow = rdfirst_ptr(grow_);
+    uint8_t *const gout = rdfirst_ptr(gout_);
+    const uint32_t ntok = rdfirst(ntok_), npieces = rdfirst(npieces_), cap = rdfirst(cap_);
+    uint32_t opos = rdfirst(opos_);
     const ChunkLds C = chunk_lds(L);
+    lds_u8 *const img = (lds_u8 *)C.out;
+    if (ntok == 0) return true;
     const uint64_t le_mask = lanemask_lt() | (1ull << lane);
-    const uint32_t pfirst = lane < npieces ? L.pk[lane] >> 14 : 0xffffffffu;  // first stream index of piece `lane`
+    const uint32_t mypk = lane < npieces ? L.pk[lane] : 0u;                // descriptor of piece `lane`
+    const uint32_t pfirst = lane < npieces ? mypk >> 14 : 0xffffffffu;      // its first stream index
+    // Token g + lane of the stream (lanes behind the end re-read the last token: no branch around the load).  The piece a
+    // token lies in = pieces that start at or before it: those in front of the group by ballot, those inside it through
+    // a 64-bit mask of their start positions put together with scalar instructions (no LDS round trip, no wait).
+    auto fetch = [&](uint32_t g) -> uint32_t {
+        const uint32_t rel = pfirst - g;
+        uint64_t bm = __ballot(rel < 64u), m = 0;
+        while (bm) {
+            const uint32_t k = (uint32_t)__ffsll((long long)bm) - 1u;
+            m |= 1ull << rdlane(rel, k);
+            bm &= bm - 1ull;
+        }
+        const uint32_t before = (uint32_t)__popcll(__ballot(pfirst < g));
+        uint32_t k = before + (uint32_t)__popcll(m & le_mask) - 1u;
+        k = k < 64u ? k : 63u;
+        uint32_t t = g + lane;
+        t = t < ntok ? t : ntok - 1u;
+        const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)mypk);
+        return grow[((d >> 8) & 63u) * ROW_TOKENS + (d & 255u) + (t - (d >> 14))];
+    };
     uint32_t c0 = 0;  // tokens executed so far
+    WSYNC();          // the walk's and the resolve's LDS reads are done
+    // Token groups c0, c0 + 64, c0 + 128, c0 + 192 are on their way in tq0..tq3; the group loop is unrolled four times
+    // so that every slot is a fixed register (a rotating array would be moved, and a move waits for its load).
+#ifndef CHIP_FLUSH_PF
+#define CHIP_FLUSH_PF 1  // 4 = four token groups in flight in fixed registers (measured slower: spills)
+#endif
+    constexpr uint32_t AHEAD = 64u * (CHIP_FLUSH_PF - 1);
+    uint32_t tq0 = fetch(0);
+#if CHIP_FLUSH_PF == 4
+    uint32_t tq1 = fetch(64), tq2 = fetch(128), tq3 = fetch(192);
+#endif
     while (c0 < ntok) {
         STAT_ADD(13, 1);
-        // ---- gather: token c0 + 64 j + lane -> tmp[j]; the piece a token lies in = pieces that start at or before it
-        uint32_t tmp[CHUNK_GROUPS];
-        WSYNC();  // the previous chunk's LDS reads are done
-#pragma unroll
-        for (uint32_t j = 0; j < CHUNK_GROUPS; j++) {
-            const uint32_t g = c0 + 64u * j;
-            tmp[j] = 0;
-            if (g < ntok) {
-                if (lane < 2) C.pmask[lane] = 0;
-                LSYNC();  // LDS only: the token loads of the groups before stay in flight
-                const uint32_t rel = pfirst - g;
-                if (rel < 64u) atomicOr(&C.pmask[rel >> 5], 1u << (rel & 31u));
-                LSYNC();
-                const uint64_t m = (uint64_t)C.pmask[0] | ((uint64_t)C.pmask[1] << 32);
-                const uint32_t before = (uint32_t)__popcll(__ballot(pfirst < g));
-                uint32_t k = before + (uint32_t)__popcll(m & le_mask) - 1u;
-                k = k < 64u ? k : 63u;
-                uint32_t t = g + lane;
-                t = t < ntok ? t : ntok - 1u;  // lanes behind the end re-read the last token: no branch around the load
-                const uint32_t d = L.pk[k];
-                tmp[j] = grow[((d >> 8) & 63u) * ROW_TOKENS + (d & 255u) + (t - (d >> 14))];
-            }
-        }
-        // ---- chunk setup: output offsets (relative to the dword-aligned address below the chunk's first byte)
         const uint32_t mis = (uint32_t)((uintptr_t)(gout + opos) & 3u);
         uint8_t *const base = gout + opos - mis;  // byte x of the chunk lives at base[x]; base is dword aligned
-        if (lane < CHUNK_BYTES / 32) {
-            C.heads[lane] = 0;
-            C.dmap[lane] = 0;
-        }
-        WSYNC();
-        uint32_t run = mis, nc = 0;
-        bool too_far = false;
-#pragma unroll
-        for (uint32_t j = 0; j < CHUNK_GROUPS; j++) {
-            const uint32_t g = c0 + 64u * j;
-            if (g >= ntok) break;
-            const bool valid = g + lane < ntok;
-            const uint32_t t = tmp[j];
+        const bool glob_ok = cap - opos >= 16u;
+        uint32_t run = mis, nq = 0, qh = 0;
+        bool too_far = false, inflight = false;
+        Round R;
+        // one token group out of slot `t`; refills the slot; returns false when the chunk ends here
+        auto step = [&](uint32_t &tslot) -> bool {
+            const uint32_t t = tslot;
+            const bool valid = c0 + lane < ntok;
             const uint32_t len = t & 0x1ffu, val = t >> 9;
             const uint32_t olen = valid ? (len ? len : 1u) : 0u;
             const uint32_t incl = wave_incl_scan(olen);
@@ -555,140 +682,65 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
             // "invalid distance too far back": the distance reaches before the first output byte
             const bool bad = len && val > opos + start - mis;
             const uint64_t stopm = __ballot(valid && (!fits || bad));
-            const uint32_t nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : (uint32_t)__popcll(__ballot(valid));
-            if (lane < nacc) {
-                C.tok[64u * j + lane] = t;
-                C.start[64u * j + lane] = (uint16_t)start;
-                atomicOr(&C.heads[start >> 5], 1u << (start & 31u));
+            uint32_t nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : (uint32_t)__popcll(__ballot(valid));
+            // a group that does not fit is left whole to the next chunk unless the chunk is empty (long matches: 64
+            // tokens can be 16 KB) or the stop is an error
+            const bool badstop = stopm && rdlane(bad ? 1u : 0u, nacc) != 0 && rdlane(fits ? 1u : 0u, nacc) != 0;
+            if (stopm && !badstop && run != mis) nacc = 0;
+            const bool acc = lane < nacc;
+            if (acc && !len) img[start] = (uint8_t)val;
+            const uint64_t mm = __ballot(acc && len);
+            if (acc && len) {
+                const uint32_t qi = (nq + (uint32_t)__popcll(mm & lanemask_lt())) & (MQ_CAP - 1u);
+                C.mq_x[qi] = start;
+                C.mq_ld[qi] = len | (val << 16);
             }
-            nc += nacc;
+            nq += (uint32_t)__popcll(mm);
+            c0 += nacc;
+            bool more = true;
             if (stopm) {
-                too_far = rdlane(bad ? 1u : 0u, nacc) != 0 && rdlane(fits ? 1u : 0u, nacc) != 0;
-                run = rdlane(start, nacc);
-                break;
-            }
-            run = rdlane(run + incl, 63u);
-            if (nacc < 64u) break;
-        }
-        const uint32_t xend = run;  // offsets [mis, xend) are produced by this chunk
-        WSYNC();
-        {
-            const uint32_t hw = lane < CHUNK_BYTES / 32 ? C.heads[lane] : 0u;
-            const uint32_t pc = (uint32_t)__popc(hw);
-            const uint32_t ex = wave_incl_scan(pc) - pc;
-            if (lane < CHUNK_BYTES / 32) C.wpre[lane] = ex;
-        }
-        WSYNC();
-        STAT_ACC(16);
-        // ---- steps
-        uint32_t lo = mis;  // everything below is already in memory
-        uint8_t *const outb = (uint8_t *)C.out;
-        while (lo < xend) {
-            STAT_ADD(14, 1);
-            const uint32_t x0 = (lo & ~3u) + 4u * lane;
-            const uint32_t wi = x0 >> 5, sh = x0 & 31u;
-            const bool inmap = wi < CHUNK_BYTES / 32;
-            const uint32_t hw = inmap ? C.heads[wi] : 0u, wp = inmap ? C.wpre[wi] : 0u;
-            int32_t r[4];
-            uint32_t tk[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++)  // token starts at or below x0 + j, minus one: -1 (a harmless read in front of the
-                r[j] = (int32_t)(wp + (uint32_t)__popc(hw & ((2u << (sh + j)) - 1u))) - 1;  // array) only for bytes below the chunk
-#pragma unroll
-            for (int j = 0; j < 4; j++) tk[j] = C.tok[r[j]];
-            // the step ends 256 bytes behind its dword-aligned start or at the chunk end
-            uint32_t e = (lo & ~3u) + 256u;
-            e = e < xend ? e : xend;
-            uint32_t byte[4], srcx[4];
-            bool want[4], isld[4];
-            bool overlap = false;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint32_t x = x0 + j;
-                const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
-                srcx[j] = x - val;  // right unless the match overlaps itself (distance < length)
-                want[j] = (x >= lo) & (x < e);
-                isld[j] = want[j] & (len != 0);
-                overlap = overlap | (isld[j] & (val < len));
-                byte[j] = val & 0xffu;
-            }
-            if (__any(overlap)) {
-                // a self-overlapping match repeats its first `distance` bytes: source = start - distance + (offset mod distance)
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    const uint32_t len = tk[j] & 0x1ffu, val = tk[j] >> 9;
-                    const uint32_t st = C.start[r[j]];
-                    const uint32_t off = x0 + j - st;
-                    const uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)val));  // off / val for off, val < 512
-                    if (val < len) srcx[j] = st - val + (off - q * val);
-                }
-            }
-            // sources below the chunk come from the output in HBM, sources below this step from the chunk's LDS image;
-            // a byte whose source lies inside this very step waits (rare: short distances)
-            uint8_t ld[4] = {0, 0, 0, 0};
-            uint32_t dm = 0;  // this lane's waiting bytes
-#ifndef CHIP_EXP_NOLOAD
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (isld[j] && (int32_t)srcx[j] < (int32_t)mis) ld[j] = base[(int32_t)srcx[j]];
-#endif
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const bool inchunk = isld[j] && (int32_t)srcx[j] >= (int32_t)mis;
-                if (inchunk && srcx[j] < lo) ld[j] = outb[srcx[j]];
-                dm |= (inchunk && srcx[j] >= lo) ? 1u << j : 0u;
-            }
-            uint32_t word = 0, mask = 0;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                byte[j] = isld[j] ? (uint32_t)ld[j] : byte[j];
-                word |= byte[j] << (8 * j);
-                mask |= want[j] ? 1u << j : 0u;
-            }
-            mask &= ~dm;
-            if (mask == 15u) {
-                C.out[x0 >> 2] = word;
-            } else if (mask) {
-#pragma unroll
-                for (int j = 0; j < 4; j++)
-                    if ((mask >> j) & 1u) outb[x0 + j] = (uint8_t)(word >> (8 * j));
-            }
-            if (__any(dm != 0)) {
-                // waiting bytes are flagged in dmap; each round copies those whose source is not itself waiting
-                // (the lowest waiting byte never is, so every round makes progress)
-                if (dm) atomicOr(&C.dmap[wi], dm << sh);
-                WSYNC();
-                while (__any(dm != 0)) {
-                    uint32_t got = 0;
-                    uint8_t b[4] = {0, 0, 0, 0};
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        if ((dm >> j) & 1u) {
-                            const uint32_t sx = srcx[j];
-                            if (!((C.dmap[sx >> 5] >> (sx & 31u)) & 1u)) {
-                                b[j] = outb[sx];
-                                got |= 1u << j;
-                            }
-                        }
-                    }
-                    WSYNC();  // every test of this round comes before any flag is cleared
-#pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if ((got >> j) & 1u) outb[x0 + j] = b[j];
-                    if (got) atomicAnd(&C.dmap[wi], ~(got << sh));
-                    dm &= ~got;
-                    WSYNC();
-                }
+                too_far = badstop;
+                if (nacc) run = rdlane(start, nacc);
+                more = false;
             } else {
-                WSYNC();  // the next step may read these bytes
+                run = rdlane(run + incl, 63u);
+                tslot = fetch(c0 + AHEAD);
+                more = c0 < ntok;
             }
-            lo = e;
+            LSYNC();  // literals and queue entries are in LDS
+            STAT_ACC(16);
+            if (inflight) round_finish(R, C, base, mis STAT_ARG);  // its loads went out one token group ago
+            inflight = nq - qh >= 64u;
+            if (inflight) {
+                round_issue(R, C, base, mis, qh, 64u, glob_ok);
+                qh += 64u;
+            }
+            STAT_ACC(17);
+            return more;
+        };
+#if CHIP_FLUSH_PF == 4
+        while (step(tq0) && step(tq1) && step(tq2) && step(tq3)) {}
+        if (c0 < ntok) {  // the stream goes on in the next chunk: its first groups, from wherever this one stopped
+            tq0 = fetch(c0);
+            tq1 = fetch(c0 + 64u);
+            tq2 = fetch(c0 + 128u);
+            tq3 = fetch(c0 + 192u);
         }
+#else
+        while (step(tq0)) {}
+        if (c0 < ntok) tq0 = fetch(c0);
+#endif
+        if (inflight) round_finish(R, C, base, mis STAT_ARG);
+        if (nq != qh) {
+            round_issue(R, C, base, mis, qh, nq - qh, glob_ok);
+            round_finish(R, C, base, mis STAT_ARG);
+        }
+        STAT_ACC(17);
+        const uint32_t xend = run;  // offsets [mis, xend) are produced by this chunk
         // ---- the finished chunk: offsets [mis, min(xend, xcap)) of the LDS image go to HBM
         {
             const uint32_t xcap = cap - (opos - mis);
             const uint32_t xe = xend < xcap ? xend : xcap;
-#ifndef CHIP_EXP_NOSTORE
             for (uint32_t xq = 4u * lane; xq < xe; xq += 256u) {
                 const uint32_t wv = C.out[xq >> 2];
                 if (xq >= mis && xq + 4u <= xe) {
@@ -699,13 +751,13 @@ __device__ bool flush_tokens(WaveLds &L, const uint32_t *grow, uint32_t ntok, ui
                         if (xq + j >= mis && xq + j < xe) base[xq + j] = (uint8_t)(wv >> (8 * j));
                 }
             }
-#endif
         }
-        STAT_ACC(17);
+        WSYNC();  // the next chunk overwrites the image and may load these bytes from memory
+        STAT_ACC(18);
         opos += xend - mis;
-        c0 += nc;
+        opos_ = opos;
         if (opos > cap) {
-            opos = cap;
+            opos_ = cap;
             status = CHIP_NEED_OUTPUT;
             return false;
         }
@@ -734,7 +786,7 @@ enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 
 // Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them
 // into gout as it goes.  On return `pos` is behind the end-of-block code (status stays
 // ST_RUNNING) or status holds the reason decoding stopped.
-__device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
+__device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
                              const uint32_t cap, int32_t &status, uint32_t *grow, const uint32_t xt_bits STAT_PARAM)
 {
     const uint32_t lane = lane_id();
@@ -883,7 +935,7 @@ __device__ void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t
 
 
 // After both alphabets are built: try to replace sorted[] by sub-tables (see build_subtables).
-__device__ void finish_tables(WaveLds &L)
+__device__ CHIP_PHASE_FN void finish_tables(WaveLds &L)
 {
     uint32_t *scratch = L.inbuf;  // free: the block header is parsed and decode_block stages its own window
     WSYNC();
