@@ -92,7 +92,6 @@ static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0,
 constexpr int ROW_WORDS = S_BITS / 32;  // boundary bitmap words per lane (own segment only)
 constexpr int IN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
 static_assert(IN_DW >= 320, "table-build scratch lives in the input window");
-static_assert(ROW_TOKENS <= 256, "piece descriptors keep the row index in 8 bits");
 constexpr size_t SCRATCH_WORDS_PER_WAVE = (size_t)64 * ROW_TOKENS;
 
 // token: [8:0] match length (0 = literal), [31:9] literal byte or match distance
@@ -121,7 +120,7 @@ struct alignas(16) WaveLds {
             uint8_t lens[320];
         } hdr;
     };
-    uint32_t pk[64];        // k-th piece of the true stream: first row index | row (lane) << 8 | first stream index << 14
+    uint32_t pk[128];       // k-th piece of the true stream: [2k] its first stream index, [2k+1] scratch word index of its first token minus that
     HuffMeta lit_h, dist_h;
     uint32_t use_sub;  // long codes resolve through sub-tables living in lit_sorted/dist_sorted
 };
@@ -195,10 +194,11 @@ __device__ __forceinline__ uint32_t long_lookup(const LongCodes<ROOT> &lc, const
 
 // Build a canonical Huffman decode table from code lengths (RFC 1951 sec. 3.2.2) with zlib's
 // acceptance rules.  Wave-cooperative; lens[] lives in LDS.  Returns 0 or -1 (uniform).
-__device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n, int type, int root, uint32_t *lut, uint32_t *sorted,
+__device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n_, int type, int root, uint32_t *lut, uint32_t *sorted,
                            HuffMeta &H)
 {
     const uint32_t lane = lane_id();
+    const int n = (int)rdfirst((uint32_t)n_);
     if (lane < 16) L.hdr.count[lane] = 0;
     WSYNC();
     for (int s = lane; s < n; s += 64) {
@@ -210,7 +210,7 @@ __device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n,
     int left = 1;
     bool over = false;
     for (uint32_t l = 1; l <= 15; l++) {
-        uint32_t c = L.hdr.count[l];
+        const uint32_t c = rdfirst(L.hdr.count[l]);  // every lane reads the same word: say that it is uniform
         if (c) maxlen = l;
         left = (left << 1) - (int)c;
         if (left < 0) over = true;
@@ -354,6 +354,16 @@ __device__ __forceinline__ void win_bits(const WaveLds &L, const InWin &w, uint3
     hi = __builtin_amdgcn_alignbit(d2, d1, sh);
 }
 
+// the same at a wave-uniform position: the result is the same in every lane, and is handed back as such (scalar
+// registers; branches on header fields become scalar branches instead of exec-mask regions)
+__device__ __forceinline__ void win_bits_uniform(const WaveLds &L, const InWin &w, uint32_t pos, uint32_t &lo, uint32_t &hi)
+{
+    uint32_t l, h;
+    win_bits(L, w, pos, l, h);
+    lo = rdfirst(l);
+    hi = rdfirst(h);
+}
+
 __device__ __forceinline__ uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
 
 
@@ -471,7 +481,7 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 // depend on matches of the same round, self-overlapping, very long or chunk-straddling matches) is done
 // in further passes or, when few, one match at a time by the whole wave.
 #ifndef CHIP_CHUNK_BYTES
-#define CHIP_CHUNK_BYTES 3072
+#define CHIP_CHUNK_BYTES 2560
 #endif
 #ifndef CHIP_COPY_LANE_MAX
 #define CHIP_COPY_LANE_MAX 32
@@ -480,23 +490,25 @@ constexpr uint32_t CHUNK_BYTES = CHIP_CHUNK_BYTES;
 constexpr uint32_t COPY_LANE_MAX = CHIP_COPY_LANE_MAX;
 constexpr uint32_t MQ_CAP = 128;  // queued matches: at most 63 left over + 64 new
 constexpr uint32_t IMG_WORDS = CHUNK_BYTES / 4 + 8;  // + room for the 16-byte reads that run past a source's end
-constexpr uint32_t CHUNK_LDS_WORDS = IMG_WORDS + 2 * MQ_CAP;
+constexpr uint32_t TOK_RING = 4;   // token groups on their way from the scratch rows into LDS (LDS-DMA: no registers held)
+constexpr uint32_t CHUNK_LDS_WORDS = IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING;
 static_assert(CHUNK_LDS_WORDS <= IN_DW + ROW_WORDS * 64, "the chunk state lives in the input window and the boundary rows");
 static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0, "geometry");
 
 struct ChunkLds {
-    uint32_t *out;    // [IMG_WORDS] the chunk's output bytes by offset (offset 0 = the dword-aligned address below the chunk)
-    uint32_t *mq_x;   // [MQ_CAP] queued match: offset of its first output byte
-    uint32_t *mq_ld;  // [MQ_CAP] queued match: length | distance << 16
+    uint32_t *out;  // [IMG_WORDS] the chunk's output bytes by offset (offset 0 = the dword-aligned address below the chunk)
+    uint2 *mq;      // [MQ_CAP] queued match: .x offset of its first output byte, .y length | distance << 16
+    uint32_t *tok;  // [64 * TOK_RING] token groups, written by global_load_lds_dword
 };
 
 __device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
 {
     static_assert(offsetof(WaveLds, rows) == offsetof(WaveLds, inbuf) + sizeof(uint32_t) * IN_DW, "window and rows are contiguous");
+    static_assert((offsetof(WaveLds, inbuf) + 4 * IMG_WORDS) % 8 == 0, "queue entries are 8-byte aligned");
     ChunkLds c;
     c.out = L.inbuf;
-    c.mq_x = c.out + IMG_WORDS;
-    c.mq_ld = c.mq_x + MQ_CAP;
+    c.mq = (uint2 *)(c.out + IMG_WORDS);
+    c.tok = c.out + IMG_WORDS + 2 * MQ_CAP;
     return c;
 }
 
@@ -558,8 +570,9 @@ __device__ __forceinline__ void round_issue(Round &r, const ChunkLds &C, const u
     const uint32_t lane = lane_id();
     const bool act = lane < nr;
     const uint32_t qi = (qh + lane) & (MQ_CAP - 1u);
-    r.x = act ? C.mq_x[qi] : 0u;
-    const uint32_t ld = act ? C.mq_ld[qi] : 0u;
+    const uint2 e = C.mq[qi];
+    r.x = e.x;
+    const uint32_t ld = act ? e.y : 0u;
     r.len = ld & 0xffffu;
     r.dist = ld >> 16;
     const int32_t sx = (int32_t)r.x - (int32_t)r.dist;
@@ -628,133 +641,155 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
     const ChunkLds C = chunk_lds(L);
     lds_u8 *const img = (lds_u8 *)C.out;
     if (ntok == 0) return true;
-    const uint64_t le_mask = lanemask_lt() | (1ull << lane);
-    const uint32_t mypk = lane < npieces ? L.pk[lane] : 0u;                // descriptor of piece `lane`
-    const uint32_t pfirst = lane < npieces ? mypk >> 14 : 0xffffffffu;      // its first stream index
+    // piece `lane`: first stream index, and what to add to a stream index to get the token's word in the scratch rows
+    const uint32_t pfirst = lane < npieces ? L.pk[2u * lane] : 0xffffffffu;
+    const uint32_t pdelta = lane < npieces ? L.pk[2u * lane + 1u] : 0u;
     // Token g + lane of the stream (lanes behind the end re-read the last token: no branch around the load).  The piece a
-    // token lies in = pieces that start at or before it: those in front of the group by ballot, those inside it through
-    // a 64-bit mask of their start positions put together with scalar instructions (no LDS round trip, no wait).
-    auto fetch = [&](uint32_t g) -> uint32_t {
+    // token lies in = pieces that start at or before it, minus one: `before` pieces start in front of the group (kept
+    // up to date by the caller), those inside it are found through a 64-bit mask of their start positions, put together
+    // with scalar instructions; a DPP-free count of the mask bits below each lane and one cross-lane read finish it.
+    uint32_t before = 0;  // pieces that start before stream index gnext
+    uint32_t gnext = 0;   // stream index the next fetch() asks for
+    uint32_t slot_w = 0;  // ring slot the next fetch() fills
+    const uint32_t tok_lds = rdfirst((uint32_t)(uintptr_t)(LDS_AS uint32_t *)C.tok);  // LDS byte address of the ring
+    // The load goes straight into LDS (global_load_lds_dword: LDS address = M0 + 4 * lane): no register is held while it
+    // is in flight, and the compiler does not wait for it -- issue() and the explicit vmcnt wait in front of a slot's
+    // first read keep the count: a slot's load is complete once at most TOK_RING - 1 younger loads are outstanding.
+    auto fetch = [&]() {
+        const uint32_t g = gnext;
         const uint32_t rel = pfirst - g;
         uint64_t bm = __ballot(rel < 64u), m = 0;
+        const uint32_t inside = (uint32_t)__popcll(bm);
         while (bm) {
             const uint32_t k = (uint32_t)__ffsll((long long)bm) - 1u;
             m |= 1ull << rdlane(rel, k);
             bm &= bm - 1ull;
         }
-        const uint32_t before = (uint32_t)__popcll(__ballot(pfirst < g));
-        uint32_t k = before + (uint32_t)__popcll(m & le_mask) - 1u;
-        k = k < 64u ? k : 63u;
+        // pieces starting at or before lane t of the group: before + bits 0..t of m = before + (m & 1) + bits below t of m >> 1
+        const uint32_t base = before + (uint32_t)(m & 1ull) - 1u;
+        const uint64_t m1 = m >> 1;
+        const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, base));
+        const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)pdelta);
         uint32_t t = g + lane;
         t = t < ntok ? t : ntok - 1u;
-        const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)mypk);
-        return grow[((d >> 8) & 63u) * ROW_TOKENS + (d & 255u) + (t - (d >> 14))];
+        before += inside;
+        gnext = g + 64u;
+        const uint32_t *src = grow + (t + d);
+        const uint32_t dst = tok_lds + 256u * slot_w;
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(src), "s"(dst)
+                     : "memory");
+        slot_w = (slot_w + 1u) & (TOK_RING - 1u);
     };
-    uint32_t c0 = 0;  // tokens executed so far
-    WSYNC();          // the walk's and the resolve's LDS reads are done
-    // Token groups c0, c0 + 64, c0 + 128, c0 + 192 are on their way in tq0..tq3; the group loop is unrolled four times
-    // so that every slot is a fixed register (a rotating array would be moved, and a move waits for its load).
-#ifndef CHIP_FLUSH_PF
-#define CHIP_FLUSH_PF 1  // 4 = four token groups in flight in fixed registers (measured slower: spills)
-#endif
-    constexpr uint32_t AHEAD = 64u * (CHIP_FLUSH_PF - 1);
-    uint32_t tq0 = fetch(0);
-#if CHIP_FLUSH_PF == 4
-    uint32_t tq1 = fetch(64), tq2 = fetch(128), tq3 = fetch(192);
-#endif
-    while (c0 < ntok) {
-        STAT_ADD(13, 1);
-        const uint32_t mis = (uint32_t)((uintptr_t)(gout + opos) & 3u);
-        uint8_t *const base = gout + opos - mis;  // byte x of the chunk lives at base[x]; base is dword aligned
-        const bool glob_ok = cap - opos >= 16u;
-        uint32_t run = mis, nq = 0, qh = 0;
-        bool too_far = false, inflight = false;
-        Round R;
-        // one token group out of slot `t`; refills the slot; returns false when the chunk ends here
-        auto step = [&](uint32_t &tslot) -> bool {
-            const uint32_t t = tslot;
-            const bool valid = c0 + lane < ntok;
-            const uint32_t len = t & 0x1ffu, val = t >> 9;
-            const uint32_t olen = valid ? (len ? len : 1u) : 0u;
-            const uint32_t incl = wave_incl_scan(olen);
-            const uint32_t start = run + incl - olen;
-            const bool fits = run + incl <= CHUNK_BYTES;
-            // "invalid distance too far back": the distance reaches before the first output byte
-            const bool bad = len && val > opos + start - mis;
-            const uint64_t stopm = __ballot(valid && (!fits || bad));
-            uint32_t nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : (uint32_t)__popcll(__ballot(valid));
-            // a group that does not fit is left whole to the next chunk unless the chunk is empty (long matches: 64
-            // tokens can be 16 KB) or the stop is an error
-            const bool badstop = stopm && rdlane(bad ? 1u : 0u, nacc) != 0 && rdlane(fits ? 1u : 0u, nacc) != 0;
-            if (stopm && !badstop && run != mis) nacc = 0;
-            const bool acc = lane < nacc;
-            if (acc && !len) img[start] = (uint8_t)val;
-            const uint64_t mm = __ballot(acc && len);
-            if (acc && len) {
-                const uint32_t qi = (nq + (uint32_t)__popcll(mm & lanemask_lt())) & (MQ_CAP - 1u);
-                C.mq_x[qi] = start;
-                C.mq_ld[qi] = len | (val << 16);
-            }
-            nq += (uint32_t)__popcll(mm);
-            c0 += nacc;
-            bool more = true;
-            if (stopm) {
-                too_far = badstop;
-                if (nacc) run = rdlane(start, nacc);
-                more = false;
-            } else {
-                run = rdlane(run + incl, 63u);
-                tslot = fetch(c0 + AHEAD);
-                more = c0 < ntok;
-            }
-            LSYNC();  // literals and queue entries are in LDS
-            STAT_ACC(16);
-            if (inflight) round_finish(R, C, base, mis STAT_ARG);  // its loads went out one token group ago
-            inflight = nq - qh >= 64u;
-            if (inflight) {
-                round_issue(R, C, base, mis, qh, 64u, glob_ok);
-                qh += 64u;
-            }
-            STAT_ACC(17);
-            return more;
-        };
-#if CHIP_FLUSH_PF == 4
-        while (step(tq0) && step(tq1) && step(tq2) && step(tq3)) {}
-        if (c0 < ntok) {  // the stream goes on in the next chunk: its first groups, from wherever this one stopped
-            tq0 = fetch(c0);
-            tq1 = fetch(c0 + 64u);
-            tq2 = fetch(c0 + 128u);
-            tq3 = fetch(c0 + 192u);
+    WSYNC();  // the walk's and the resolve's LDS reads are done (the chunk state takes their place)
+    uint32_t c0 = 0;      // tokens executed so far
+    uint32_t slot_r = 0;  // ring slot of the group at c0
+#pragma unroll
+    for (uint32_t k = 0; k < TOK_RING; k++) fetch();
+    // ---- chunk state (every piece of code below exists once: no closures, everything stays in registers)
+    bool fresh = true;  // a chunk starts with the next group
+    uint32_t mis = 0, run = 0, nq = 0, qh = 0, prod0 = 0;
+    uint8_t *base = gout;
+    bool glob_ok = false, inflight = false;
+    Round R;
+    for (;;) {
+        if (fresh) {
+            STAT_ADD(13, 1);
+            mis = (uint32_t)((uintptr_t)(gout + opos) & 3u);
+            base = gout + opos - mis;  // byte x of the chunk lives at base[x]; base is dword aligned
+            glob_ok = cap - opos >= 16u;
+            run = mis;
+            prod0 = opos - mis;  // output bytes in front of offset 0
+            nq = qh = 0;
+            fresh = false;
         }
-#else
-        while (step(tq0)) {}
-        if (c0 < ntok) tq0 = fetch(c0);
-#endif
-        if (inflight) round_finish(R, C, base, mis STAT_ARG);
-        if (nq != qh) {
-            round_issue(R, C, base, mis, qh, nq - qh, glob_ok);
-            round_finish(R, C, base, mis STAT_ARG);
+        static_assert(TOK_RING == 4, "the wait below counts three younger ring loads");
+        asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the load into slot_r has landed
+        const uint32_t t = C.tok[64u * slot_r + lane];
+        const uint32_t nvalid = ntok - c0 < 64u ? ntok - c0 : 64u;
+        const uint32_t len = t & 0x1ffu, val = t >> 9;
+        const uint32_t olen = lane < nvalid ? (len > 1u ? len : 1u) : 0u;
+        const uint32_t incl = wave_incl_scan(olen);
+        const uint32_t start = run + incl - olen;
+        // stops: the first token that does not fit the chunk, or with an "invalid distance too far back" (the distance
+        // reaches before the first output byte)
+        const uint64_t lenm = __ballot(len != 0);
+        const uint64_t validm = nvalid == 64u ? ~0ull : (1ull << nvalid) - 1ull;
+        const uint64_t nofit = __ballot(incl > CHUNK_BYTES - run) & validm;
+        const uint64_t badm = __ballot(val > prod0 + start) & lenm & validm;
+        const uint64_t stopm = nofit | badm;
+        uint32_t nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : nvalid;
+        // a group that does not fit is left whole to the next chunk (the prefetched group stays the right one) unless the
+        // chunk is empty (long matches: 64 tokens can be 16 KB) or the stop is an error
+        const bool too_far = stopm != 0 && ((badm & ~nofit) >> nacc) & 1ull;
+        if (stopm && !too_far && run != mis) nacc = 0;
+        if (lane < nacc && len == 0) img[start] = (uint8_t)val;
+        const uint64_t mm = lenm & (nacc == 64u ? ~0ull : (1ull << nacc) - 1ull);
+        if (lane < nacc && len != 0) {
+            const uint32_t qi = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, nq)) & (MQ_CAP - 1u);
+            C.mq[qi] = make_uint2(start, len | (val << 16));
+        }
+        nq += (uint32_t)__popcll(mm);
+        c0 += nacc;
+        if (stopm) {
+            if (nacc) run = rdlane(start, nacc);
+        } else {
+            run += rdlane(incl, 63u);
+        }
+        const bool ending = stopm != 0 || c0 >= ntok;  // the chunk ends with this group
+        LSYNC();  // literals and queue entries are in LDS; the slot's tokens are in registers
+        STAT_ACC(16);
+        // ---- match rounds.  A round's source loads are started as soon as 64 matches are queued and it is finished
+        // when the next 64 are (about three token groups later: the loads have landed by then), or at the chunk's end.
+        if (nq - qh >= 64u || ending) {
+            do {
+                if (inflight) {
+                    round_finish(R, C, base, mis STAT_ARG);
+                    inflight = false;
+                }
+                const uint32_t pq = nq - qh;
+                if (pq >= 64u || (ending && pq != 0)) {
+                    const uint32_t nr = pq < 64u ? pq : 64u;
+                    round_issue(R, C, base, mis, qh, nr, glob_ok);
+                    qh += nr;
+                    inflight = true;
+                }
+            } while (ending && inflight);
         }
         STAT_ACC(17);
-        const uint32_t xend = run;  // offsets [mis, xend) are produced by this chunk
-        // ---- the finished chunk: offsets [mis, min(xend, xcap)) of the LDS image go to HBM
+        // ---- the token ring (behind the rounds: their waits do not hold a ring load that was only just issued)
+        if (nacc == 64u) {
+            fetch();  // refills the slot just read: the group TOK_RING ahead
+            slot_r = (slot_r + 1u) & (TOK_RING - 1u);
+        } else if (nacc != 0 && c0 < ntok) {  // a partly taken group: the stream moves by less than a group, the ring starts over
+            gnext = c0;
+            before = (uint32_t)__popcll(__ballot(pfirst < c0));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // no load of the old ring is left to land on the new one
+            slot_r = slot_w = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < TOK_RING; k++) fetch();
+        }
+        if (!ending) continue;
+        // ---- the finished chunk: offsets [mis, min(run, capacity)) of the LDS image go to HBM
         {
             const uint32_t xcap = cap - (opos - mis);
-            const uint32_t xe = xend < xcap ? xend : xcap;
+            const uint32_t xe = run < xcap ? run : xcap;
             for (uint32_t xq = 4u * lane; xq < xe; xq += 256u) {
                 const uint32_t wv = C.out[xq >> 2];
                 if (xq >= mis && xq + 4u <= xe) {
                     *(uint32_t *)(base + xq) = wv;
                 } else {
 #pragma unroll
-                    for (int j = 0; j < 4; j++)
-                        if (xq + j >= mis && xq + j < xe) base[xq + j] = (uint8_t)(wv >> (8 * j));
+                    for (int k = 0; k < 4; k++)
+                        if (xq + k >= mis && xq + k < xe) base[xq + k] = (uint8_t)(wv >> (8 * k));
                 }
             }
         }
         WSYNC();  // the next chunk overwrites the image and may load these bytes from memory
         STAT_ACC(18);
-        opos += xend - mis;
+        opos += run - mis;
         opos_ = opos;
         if (opos > cap) {
             opos_ = cap;
@@ -765,8 +800,9 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
             status = Z_DATA_ERROR;
             return false;
         }
+        if (c0 >= ntok) return true;
+        fresh = true;
     }
-    return true;
 }
 
 // ---- per-lane token decode (lanes are at different bit positions) ---------------------------------
@@ -790,6 +826,8 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                              const uint32_t cap, int32_t &status, uint32_t *grow, const uint32_t xt_bits STAT_PARAM)
 {
     const uint32_t lane = lane_id();
+    pos = rdfirst(pos);
+    opos = rdfirst(opos);
     const LongCodes<LIT_ROOT> lcl = load_long_codes<LIT_ROOT>(L.lit_h);
     const LongCodes<DIST_ROOT> lcd = load_long_codes<DIST_ROOT>(L.dist_h);
     const bool use_sub = rdfirst(L.use_sub) != 0;
@@ -907,7 +945,11 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         const uint32_t rz = rdlane(reason, lz), az = rdlane(aux, lz);
         // piece descriptors in stream order
         const uint64_t nonempty = __ballot(cnt != 0);
-        if (cnt) L.pk[__popcll(nonempty & lanemask_lt())] = a0 | (lane << 8) | ((incl - cnt) << 14);
+        if (cnt) {
+            const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt()), first = incl - cnt;
+            L.pk[2u * k] = first;
+            L.pk[2u * k + 1u] = lane * ROW_TOKENS + a0 - first;
+        }
         WSYNC();
         STAT_ACC(3);
         STAT_ADD(9, __popcll(onm));
@@ -984,7 +1026,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     uint32_t wrap = 0;
     int32_t format = a.format;
     if (format == CHIP_FMT_DETECT) {
-        const int32_t kind = detect_kind(gin, in_len);
+        const int32_t kind = (int32_t)rdfirst((uint32_t)detect_kind(gin, in_len));
         if (kind == CHIP_DETECT_ZSTD) return;  // the zstd kernel of the same batch call owns this unit
         if (kind == CHIP_DETECT_GZIP || kind == CHIP_DETECT_ZLIB) format = CHIP_FMT_AUTO;
         else {
@@ -1012,7 +1054,9 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     if (!resumed && format != CHIP_FMT_DEFLATE) {
         uint32_t hdr = 0;
         status = parse_wrapper(L.lit_lut, gin, in_len, format, wrap, hdr);
-        pos += hdr * 8u;
+        status = (int32_t)rdfirst((uint32_t)status);
+        wrap = rdfirst(wrap);
+        pos += rdfirst(hdr) * 8u;
     }
     if (status == ST_RUNNING) win_load(L, w, pos >> 5);
 
@@ -1030,7 +1074,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             break;
         }
         uint32_t lo, hi;
-        win_bits(L, w, pos, lo, hi);
+        win_bits_uniform(L, w, pos, lo, hi);
         last = lo & 1u;
         uint32_t type = (lo >> 1) & 3u;
         pos += 3;
@@ -1042,7 +1086,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
                 break;
             }
             win_ensure(L, w, pos);
-            win_bits(L, w, pos, lo, hi);
+            win_bits_uniform(L, w, pos, lo, hi);
             uint32_t blen = lo & 0xffffu, nlen = lo >> 16;
             if (blen != (nlen ^ 0xffffu)) {
                 status = Z_DATA_ERROR;
@@ -1086,7 +1130,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
                 break;
             }
             win_ensure(L, w, pos);
-            win_bits(L, w, pos, lo, hi);
+            win_bits_uniform(L, w, pos, lo, hi);
             uint32_t nlen = (lo & 31u) + 257, ndist = ((lo >> 5) & 31u) + 1, ncode = ((lo >> 10) & 15u) + 4;
             pos += 14;
             if (nlen > 286 || ndist > 30) {
@@ -1164,7 +1208,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             if (status != ST_RUNNING) break;
             WSYNC();
             STAT_ACC(4);
-            if (L.hdr.lens[256] == 0) {
+            if (rdfirst(L.hdr.lens[256]) == 0) {
                 status = Z_DATA_ERROR;
                 break;
             }
@@ -1193,17 +1237,17 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             status = CHIP_NEED_INPUT;
         } else if (wrap == 1) {
             uint32_t want = ((uint32_t)gin[k] << 24) | ((uint32_t)gin[k + 1] << 16) | ((uint32_t)gin[k + 2] << 8) | gin[k + 3];
-            if (wave_adler32(gout, opos) != want) status = Z_DATA_ERROR;  // incorrect data check
+            if (rdfirst(wave_adler32(gout, opos)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
             k += 4;
         } else if (in_len - k < 4) {
             status = CHIP_NEED_INPUT;
         } else {
             uint32_t want = gin[k] | ((uint32_t)gin[k + 1] << 8) | ((uint32_t)gin[k + 2] << 16) | ((uint32_t)gin[k + 3] << 24);
-            if (wave_crc32(L.lit_lut, gout, opos) != want) status = Z_DATA_ERROR;  // incorrect data check
+            if (rdfirst(wave_crc32(L.lit_lut, gout, opos)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
             else if (in_len - k < 8) status = CHIP_NEED_INPUT;
             else {
                 uint32_t isize = gin[k + 4] | ((uint32_t)gin[k + 5] << 8) | ((uint32_t)gin[k + 6] << 16) | ((uint32_t)gin[k + 7] << 24);
-                if (isize != opos) status = Z_DATA_ERROR;  // incorrect length check
+                if (rdfirst(isize) != opos) status = Z_DATA_ERROR;  // incorrect length check
             }
             k += 8;
         }
