@@ -222,6 +222,33 @@ def cpu_baseline(packed, offs, lens, n_sample, threads):
     return res
 
 
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` without torchrun: one fresh child process per GPU (this process never initialises a
+    GPU: it only counts devices), rank 0's JSON line passes through on stdout, the exit code is the worst child's."""
+    import socket
+    import subprocess
+
+    import torch
+
+    visible = torch.cuda.device_count()  # does not initialise the GPU on this image
+    if visible < n_gpus:
+        log(f"[bench] error: --gpus {n_gpus} but only {visible} GPU(s) are visible on this node")
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--worker"], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,7 +259,12 @@ def main():
     ap.add_argument("--extra", type=int, default=1, help="also measure the configs[1] variants (stored, fixed)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="units the CPU baseline decodes (about 10-30 s of CPU work in total)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)  # set by self_launch() on the ranks it starts
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # asked for several GPUs without a launcher around us: start the ranks ourselves (before anything touches a GPU)
+        sys.exit(self_launch(args.gpus))
 
     import torch
 
@@ -243,8 +275,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+        log(f"[bench] error: launched with WORLD_SIZE={world} but --gpus {args.gpus}; they must agree")
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    visible = torch.cuda.device_count()
+    if "BENCH_DEVICE_OVERRIDE" not in os.environ and local_rank >= visible:
+        log(f"[bench] error: rank {rank} needs GPU {local_rank} but only {visible} device(s) are visible")
+        sys.exit(2)
     # rehearsal knobs (not used by the driver): several ranks on one GPU need gloo, NCCL/RCCL refuses duplicate devices
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     if "BENCH_DEVICE_OVERRIDE" in os.environ:

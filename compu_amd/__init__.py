@@ -24,6 +24,7 @@ from .api import (  # noqa: F401
     ZstdOptions,
     decode_batch,
     decode_batch_host,
+    decode_batch_multi,
     encode_batch_host,
     trim,
     decoder_interface,

@@ -68,6 +68,10 @@ def lib():
     L.chip_stream_sync.argtypes = [vp]
     L.chip_decode_batch_host.restype = C.c_int
     L.chip_decode_batch_host.argtypes = [C.c_int, C.c_size_t] + [vp] * 9 + [C.c_int, C.c_size_t]
+    L.chip_decode_batch_multi.restype = C.c_int
+    L.chip_decode_batch_multi.argtypes = [C.c_int, C.c_size_t] + [vp] * 9 + [vp, C.c_int, C.c_size_t]
+    L.chip_partition_units.restype = C.c_int
+    L.chip_partition_units.argtypes = [C.c_size_t, vp, vp, C.c_int, vp]
     L.chip_encode_batch_host.restype = C.c_int
     L.chip_encode_batch_host.argtypes = [C.c_int, C.c_int, C.c_size_t] + [vp] * 8 + [C.c_int, C.c_size_t]
     L.chip_trim.restype = C.c_int
@@ -555,6 +559,16 @@ def _stream_ptr(stream):
     return C.c_void_p(getattr(stream, "cuda_stream", stream))
 
 
+def _check_tensors(pairs):
+    """Every tensor handed to a device batch call: on one GPU, contiguous, of the dtype the kernel reads it as (a CPU
+    tensor or int32 offsets would otherwise be read as device u64 offsets: a GPU fault instead of a Python error)."""
+    dev = pairs[0][0].device
+    for t, dt in pairs:
+        if not (t.is_cuda and t.is_contiguous() and t.dtype == dt and t.device == dev):
+            raise TypeError(f"expected a contiguous {dt} tensor on {dev}, got {t.dtype} on {t.device} (contiguous={t.is_contiguous()})")
+    return dev
+
+
 def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len=None, in_used=None, status=None, stream=None):
     """chip_decode_batch on device tensors: in_buf/out_buf uint8, *_off int64 (read as u64),
     in_len/out_cap/out_len/in_used int32 (read as u32), status int32.  Only enqueues."""
@@ -568,11 +582,11 @@ def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len
         in_used = torch.empty(n, dtype=torch.int32, device=dev)
     if status is None:
         status = torch.empty(n, dtype=torch.int32, device=dev)
-    for t, dt in ((in_off, torch.int64), (out_off, torch.int64), (in_len, torch.int32), (out_cap, torch.int32),
-                  (out_len, torch.int32), (in_used, torch.int32), (status, torch.int32), (in_buf, torch.uint8), (out_buf, torch.uint8)):
-        assert t.is_cuda and t.is_contiguous() and t.dtype == dt, (t.dtype, dt)
-    rc = lib().chip_decode_batch(int(fmt), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off), _dp(out_cap),
-                                 _dp(out_len), _dp(in_used), _dp(status), _stream_ptr(stream))
+    _check_tensors(((in_buf, torch.uint8), (out_buf, torch.uint8), (in_off, torch.int64), (out_off, torch.int64), (in_len, torch.int32),
+                    (out_cap, torch.int32), (out_len, torch.int32), (in_used, torch.int32), (status, torch.int32)))
+    with torch.cuda.device(dev):  # scratch and the stream come from the tensors' device, not whatever is current
+        rc = lib().chip_decode_batch(int(fmt), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off), _dp(out_cap),
+                                     _dp(out_len), _dp(in_used), _dp(status), _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"chip_decode_batch failed: {rc}")
     return out_len, in_used, status
@@ -595,6 +609,28 @@ def decode_batch_host(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, de
                                       p(status), int(device), int(slice_bytes))
     if rc != 0:
         raise RuntimeError(f"chip_decode_batch_host failed: {rc}")
+    return out_len, in_used, status
+
+
+def decode_batch_multi(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, devices=None, slice_bytes=0):
+    """chip_decode_batch_multi: host-memory units partitioned over `devices` (None = every visible GPU), one host
+    thread and two streams per device, a CHIP_FMT_DETECT batch bucketed by format first.  Returns (out_len, in_used, status)."""
+    import numpy as np
+
+    n = len(in_len)
+    in_off = np.ascontiguousarray(in_off, dtype=np.uint64)
+    in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
+    out_off = np.ascontiguousarray(out_off, dtype=np.uint64)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
+    out_len = np.zeros(n, np.uint32)
+    in_used = np.zeros(n, np.uint32)
+    status = np.zeros(n, np.int32)
+    devs = np.ascontiguousarray(devices if devices is not None else [], dtype=np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = lib().chip_decode_batch_multi(int(fmt), n, p(in_buf), p(in_off), p(in_len), p(out_buf), p(out_off), p(out_cap), p(out_len), p(in_used),
+                                       p(status), p(devs) if len(devs) else None, len(devs), int(slice_bytes))
+    if rc != 0:
+        raise RuntimeError(f"chip_decode_batch_multi failed: {rc}")
     return out_len, in_used, status
 
 
@@ -630,7 +666,9 @@ def detect_batch(in_buf, in_off, in_len, kind=None, stream=None):
     n = in_len.numel()
     if kind is None:
         kind = torch.empty(n, dtype=torch.int32, device=in_buf.device)
-    rc = lib().chip_detect_batch(n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(kind), _stream_ptr(stream))
+    dev = _check_tensors(((in_buf, torch.uint8), (in_off, torch.int64), (in_len, torch.int32), (kind, torch.int32)))
+    with torch.cuda.device(dev):
+        rc = lib().chip_detect_batch(n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(kind), _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"chip_detect_batch failed: {rc}")
     return kind
@@ -649,8 +687,11 @@ def encode_batch(fmt, level, in_buf, in_off, in_len, out_buf, out_off, out_cap, 
         out_len = torch.empty(n, dtype=torch.int32, device=dev)
     if status is None:
         status = torch.empty(n, dtype=torch.int32, device=dev)
-    rc = lib().chip_encode_batch(int(fmt), int(level), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off),
-                                 _dp(out_cap), _dp(out_len), _dp(status), _stream_ptr(stream))
+    _check_tensors(((in_buf, torch.uint8), (out_buf, torch.uint8), (in_off, torch.int64), (out_off, torch.int64), (in_len, torch.int32),
+                    (out_cap, torch.int32), (out_len, torch.int32), (status, torch.int32)))
+    with torch.cuda.device(dev):
+        rc = lib().chip_encode_batch(int(fmt), int(level), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off),
+                                     _dp(out_cap), _dp(out_len), _dp(status), _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"chip_encode_batch failed: {rc}")
     return out_len, status

@@ -11,7 +11,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
 
 #include "chip_internal.h"
 
@@ -44,6 +47,8 @@ struct Meta {
     int32_t status;
     uint32_t resume[3];  // inflate streaming: see BatchArgs::resume
 };
+
+void pipes_trim();  // defined with the host-batch pipelines below
 
 }  // namespace
 
@@ -96,7 +101,11 @@ int chip_memcpy_d2h(void *dst, const void *src, size_t size, void *stream)
     return hipMemcpyAsync(dst, src, size, hipMemcpyDeviceToHost, (hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
 int chip_stream_sync(void *stream) { return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH; }
-int chip_trim(void) { return chip::release_inflate_scratch() == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH; }
+int chip_trim(void)
+{
+    pipes_trim();  // cached host-batch pipelines of the current device (streams, staging and device buffers)
+    return chip::release_inflate_scratch() == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
+}
 
 // ---- batched decode ------------------------------------------------------------------------
 
@@ -123,6 +132,8 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     a.format = format;
     a.stats = nullptr;
     a.resume = nullptr;
+    a.sel = nullptr;
+    a.sel_n = nullptr;
 #ifdef CHIP_STATS
     a.stats = (unsigned long long *)getenv("CHIP_STATS_PTR") ? (unsigned long long *)strtoull(getenv("CHIP_STATS_PTR"), nullptr, 0) : nullptr;
 #endif
@@ -133,10 +144,23 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     case CHIP_FMT_GZIP:
     case CHIP_FMT_AUTO: e = launch_inflate(a, (hipStream_t)stream); break;
     case CHIP_FMT_ZSTD: e = launch_zstd_decode(a, 0, (hipStream_t)stream); break;
-    case CHIP_FMT_DETECT:  // both kernels see every unit; each takes the ones Detection::detect assigns to it
-        e = launch_inflate(a, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_zstd_decode(a, 0, (hipStream_t)stream);
+    case CHIP_FMT_DETECT: {
+        // Detection::detect routes every unit: one pass buckets the batch by format, then each decoder runs over its own
+        // (homogeneous) list of units
+        uint32_t *sel_i = nullptr, *sel_z = nullptr, *counts = nullptr;
+        e = route_scratch((hipStream_t)stream, n, &sel_i, &sel_z, &counts);
+        if (e == hipSuccess) e = launch_route(a, sel_i, sel_z, counts, (hipStream_t)stream);
+        BatchArgs ai = a, az = a;
+        ai.format = CHIP_FMT_AUTO;
+        ai.sel = sel_i;
+        ai.sel_n = counts;
+        az.format = CHIP_FMT_ZSTD;
+        az.sel = sel_z;
+        az.sel_n = counts + 1;
+        if (e == hipSuccess) e = launch_inflate(ai, (hipStream_t)stream);
+        if (e == hipSuccess) e = launch_zstd_decode(az, 0, (hipStream_t)stream);
         break;
+    }
     default: return CHIP_E_INVALID;
     }
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
@@ -145,142 +169,306 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
 }  // extern "C"
 
 namespace {
-// Host-memory batches: slices of consecutive units alternate between two streams (H2D -> kernel -> D2H each).
-// `launch` enqueues the device batch call for one slice; in_used may be null (encode has no such result).
-template <class Launch>
-int host_pipeline(size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len, void *out_base,
-                  const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, uint32_t *in_used, int32_t *status,
-                  int device, size_t slice_bytes, Launch launch)
+
+// the calling thread's current device is put back when a library call that switches devices returns
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (device >= 0 && device != prev) ok = hipSetDevice(device) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+};
+
+// ---- host-memory batches ------------------------------------------------------------------------------------------
+// Slices of units alternate between two pipelines (H2D -> kernel -> D2H on a stream each), so the copies of one slice
+// overlap the kernel of the other.  A slice whose units lie back to back in index order (the usual layout) moves straight
+// between the caller's memory and the device; any other layout (gaps, reverse order, overlaps, a selection of units) is
+// packed through pinned staging buffers.  Only the bytes a unit produced (out_len) are ever written to the caller's
+// output.  Pipelines (streams, device and pinned buffers) are kept per device between calls.
+struct Pipe {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    uint8_t *d_arr = nullptr, *h_arr = nullptr;  // per-unit arrays of the slice, device side and pinned host side
+    size_t arr_units = 0;
+    uint8_t *h_in = nullptr, *h_out = nullptr;   // pinned staging (packed layouts only)
+    size_t h_in_cap = 0, h_out_cap = 0;
+    // slice in flight
+    size_t k0 = 0, k1 = 0;    // positions [k0, k1) of the unit list (k1 == k0: none)
+    bool out_direct = false;
+    uint64_t o_lo = 0;
+};
+
+std::mutex g_pipe_mu;
+std::vector<Pipe *> g_pipe_pool;
+
+Pipe *pipe_get(int device)
 {
-    if (n == 0) return CHIP_OK;
-    if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !status)
-        return CHIP_E_INVALID;
-    if (!device_ok()) return CHIP_E_NO_DEVICE;
-    if (device >= 0 && hipSetDevice(device) != hipSuccess) return CHIP_E_INVALID;
+    {
+        std::lock_guard<std::mutex> lk(g_pipe_mu);
+        for (size_t i = 0; i < g_pipe_pool.size(); i++)
+            if (g_pipe_pool[i]->device == device) {
+                Pipe *p = g_pipe_pool[i];
+                g_pipe_pool.erase(g_pipe_pool.begin() + (long)i);
+                return p;
+            }
+    }
+    Pipe *p = new (std::nothrow) Pipe;
+    if (!p) return nullptr;
+    p->device = device;
+    if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete p;
+        return nullptr;
+    }
+    return p;
+}
+
+void pipe_put(Pipe *p)
+{
+    if (!p) return;
+    p->k0 = p->k1 = 0;
+    std::lock_guard<std::mutex> lk(g_pipe_mu);
+    g_pipe_pool.push_back(p);
+}
+
+void pipe_destroy(Pipe *p)  // the caller has made p->device current
+{
+    if (p->stream) {
+        (void)hipStreamSynchronize(p->stream);
+        chip::release_inflate_scratch_of(p->stream);
+        (void)hipStreamDestroy(p->stream);
+    }
+    chip_device_free(p->d_in);
+    chip_device_free(p->d_out);
+    chip_device_free(p->d_arr);
+    chip_pinned_free(p->h_arr);
+    chip_pinned_free(p->h_in);
+    chip_pinned_free(p->h_out);
+    delete p;
+}
+
+void pipes_trim()
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::vector<Pipe *> mine;
+    {
+        std::lock_guard<std::mutex> lk(g_pipe_mu);
+        for (size_t i = 0; i < g_pipe_pool.size();) {
+            if (g_pipe_pool[i]->device == dev) {
+                mine.push_back(g_pipe_pool[i]);
+                g_pipe_pool.erase(g_pipe_pool.begin() + (long)i);
+            } else {
+                i++;
+            }
+        }
+    }
+    for (Pipe *p : mine) pipe_destroy(p);
+}
+
+bool grow_dev(uint8_t *&ptr, size_t &cap, size_t need)
+{
+    if (need <= cap) return true;
+    chip_device_free(ptr);
+    cap = need + (need >> 2) + 4096;
+    return (ptr = (uint8_t *)chip_device_alloc(cap)) != nullptr || (cap = 0, false);
+}
+bool grow_pinned(uint8_t *&ptr, size_t &cap, size_t need)
+{
+    if (need <= cap) return true;
+    chip_pinned_free(ptr);
+    cap = need + (need >> 2) + 4096;
+    return (ptr = (uint8_t *)chip_pinned_alloc(cap)) != nullptr || (cap = 0, false);
+}
+
+struct HostBatch {
+    const uint8_t *in_base;
+    const uint64_t *in_off;
+    const uint32_t *in_len;
+    uint8_t *out_base;
+    const uint64_t *out_off;
+    const uint32_t *out_cap;
+    uint32_t *out_len, *in_used;  // in_used may be null (encode)
+    int32_t *status;
+    const uint32_t *sel;  // unit indices to run, ascending (null: 0 .. count)
+    size_t count;
+    size_t unit(size_t k) const { return sel ? sel[k] : k; }
+};
+
+// Runs the units of `hb` on `device` (made current by the caller).  `launch` enqueues the device batch call of one slice.
+template <class Launch>
+int host_pipeline(const HostBatch &hb, int device, size_t slice_bytes, Launch launch)
+{
+    if (hb.count == 0) return CHIP_OK;
     if (slice_bytes == 0) slice_bytes = (size_t)256 << 20;
-    struct Lane {  // one of the two pipelines
-        hipStream_t stream = nullptr;
-        uint8_t *d_in = nullptr, *d_out = nullptr;
-        size_t in_cap = 0, out_cap = 0;
-        uint8_t *d_arr = nullptr;  // per-unit arrays of the slice, device side
-        uint8_t *h_arr = nullptr;  // the same, pinned host side
-        size_t arr_units = 0;
-        size_t i0 = 0, i1 = 0;     // slice in flight (i1 == i0: none)
-        uint64_t out_lo = 0;
-    } lanes[2];
+    Pipe *pipes[2] = {pipe_get(device), pipe_get(device)};
+    if (!pipes[0] || !pipes[1]) {
+        for (Pipe *p : pipes)
+            if (p) pipe_put(p);
+        return CHIP_E_NOMEM;
+    }
     int rc = CHIP_OK;
-    // per unit: in_off u64, out_off u64, in_len u32, out_cap u32, out_len u32, in_used u32, status i32 = 36 bytes
+    // per unit on the device: in_off u64, out_off u64, in_len u32, out_cap u32 | out_len u32, in_used u32, status i32
     auto arr_bytes = [](size_t units) { return units * 36 + 64; };
-    auto reserve = [&](Lane &ln, size_t in_need, size_t out_need, size_t units) -> bool {
-        if (in_need > ln.in_cap) {
-            chip_device_free(ln.d_in);
-            ln.in_cap = in_need + (in_need >> 2) + 4096;
-            if (!(ln.d_in = (uint8_t *)chip_device_alloc(ln.in_cap))) return false;
+    // results and payload of the slice a pipeline has in flight -> the caller's memory
+    auto collect = [&](Pipe &pp) -> bool {
+        if (pp.k1 == pp.k0) return true;
+        const size_t m = pp.k1 - pp.k0;
+        if (hipStreamSynchronize(pp.stream) != hipSuccess) return false;  // kernel done, result words in h_arr
+        const uint32_t *r_len = (const uint32_t *)(pp.h_arr + m * 24), *r_used = r_len + m;
+        const int32_t *r_st = (const int32_t *)(r_len + 2 * m);
+        const uint64_t *s_out_off = (const uint64_t *)pp.h_arr + m;  // the slice's device-side output offsets
+        bool ok = true;
+        if (pp.out_direct) {
+            // runs of units whose produced bytes lie back to back go in one copy; nothing beyond out_len is written
+            size_t u = 0;
+            while (u < m && ok) {
+                size_t v = u;
+                uint64_t run_len = r_len[u];
+                while (v + 1 < m && r_len[v] == hb.out_cap[hb.unit(pp.k0 + v)] &&
+                       hb.out_off[hb.unit(pp.k0 + v)] + r_len[v] == hb.out_off[hb.unit(pp.k0 + v + 1)]) {
+                    v++;
+                    run_len += r_len[v];
+                }
+                if (run_len)
+                    ok = hipMemcpyAsync(hb.out_base + hb.out_off[hb.unit(pp.k0 + u)], pp.d_out + s_out_off[u], (size_t)run_len,
+                                        hipMemcpyDeviceToHost, pp.stream) == hipSuccess;
+                u = v + 1;
+            }
+            ok = ok && hipStreamSynchronize(pp.stream) == hipSuccess;
+        } else {
+            uint64_t span = 0;
+            for (size_t u = 0; u < m; u++)
+                if (r_len[u]) span = s_out_off[u] + r_len[u] > span ? s_out_off[u] + r_len[u] : span;
+            if (span) {
+                ok = grow_pinned(pp.h_out, pp.h_out_cap, (size_t)span);
+                ok = ok && hipMemcpyAsync(pp.h_out, pp.d_out, (size_t)span, hipMemcpyDeviceToHost, pp.stream) == hipSuccess;
+                ok = ok && hipStreamSynchronize(pp.stream) == hipSuccess;
+                for (size_t u = 0; u < m && ok; u++)
+                    if (r_len[u]) memcpy(hb.out_base + hb.out_off[hb.unit(pp.k0 + u)], pp.h_out + s_out_off[u], r_len[u]);
+            }
         }
-        if (out_need > ln.out_cap) {
-            chip_device_free(ln.d_out);
-            ln.out_cap = out_need + (out_need >> 2) + 4096;
-            if (!(ln.d_out = (uint8_t *)chip_device_alloc(ln.out_cap))) return false;
+        for (size_t u = 0; u < m; u++) {
+            const size_t g = hb.unit(pp.k0 + u);
+            hb.out_len[g] = r_len[u];
+            if (hb.in_used) hb.in_used[g] = r_used[u];
+            hb.status[g] = r_st[u];
         }
-        if (units > ln.arr_units) {
-            chip_device_free(ln.d_arr);
-            chip_pinned_free(ln.h_arr);
-            ln.arr_units = units + (units >> 2) + 64;
-            ln.d_arr = (uint8_t *)chip_device_alloc(arr_bytes(ln.arr_units));
-            ln.h_arr = (uint8_t *)chip_pinned_alloc(arr_bytes(ln.arr_units));
-            if (!ln.d_arr || !ln.h_arr) return false;
-        }
-        return true;
+        pp.k1 = pp.k0;
+        return ok;
     };
-    // results of the slice a lane has in flight -> caller's arrays (after its stream has drained)
-    auto collect = [&](Lane &ln) -> bool {
-        if (ln.i1 == ln.i0) return true;
-        if (hipStreamSynchronize(ln.stream) != hipSuccess) return false;
-        const size_t m = ln.i1 - ln.i0;
-        const uint32_t *r = (const uint32_t *)(ln.h_arr + m * 24);
-        memcpy(out_len + ln.i0, r, m * 4);
-        if (in_used) memcpy(in_used + ln.i0, r + m, m * 4);
-        memcpy(status + ln.i0, r + 2 * m, m * 4);
-        ln.i1 = ln.i0;
-        return true;
-    };
-    for (int k = 0; k < 2 && rc == CHIP_OK; k++)
-        if (hipStreamCreateWithFlags(&lanes[k].stream, hipStreamNonBlocking) != hipSuccess) rc = CHIP_E_LAUNCH;
-    size_t i = 0;
+    size_t k = 0;
     int turn = 0;
-    while (rc == CHIP_OK && i < n) {
-        // next slice: consecutive units until the byte budget is reached
-        size_t j = i;
-        uint64_t in_lo = ~0ull, in_hi = 0, o_lo = ~0ull, o_hi = 0, budget = 0;
-        while (j < n) {
-            const uint64_t a0 = in_off[j], a1 = a0 + in_len[j], b0 = out_off[j], b1 = b0 + out_cap[j];
-            if (j > i && budget + in_len[j] + out_cap[j] > slice_bytes) break;
-            budget += (uint64_t)in_len[j] + out_cap[j];
-            in_lo = a0 < in_lo ? a0 : in_lo;
-            in_hi = a1 > in_hi ? a1 : in_hi;
-            o_lo = b0 < o_lo ? b0 : o_lo;
-            o_hi = b1 > o_hi ? b1 : o_hi;
+    while (rc == CHIP_OK && k < hb.count) {
+        // next slice: positions [k, j) until the byte budget is reached; is it one back-to-back run in memory?
+        size_t j = k;
+        uint64_t budget = 0, in_sum = 0, out_sum = 0;
+        bool in_direct = true, out_direct = true;
+        while (j < hb.count) {
+            const size_t g = hb.unit(j);
+            const uint64_t need = (uint64_t)hb.in_len[g] + hb.out_cap[g];
+            if (j > k && budget + need > slice_bytes) break;
+            if (j > k) {
+                const size_t gp = hb.unit(j - 1);
+                // the next unit starts at or (by at most 15 bytes of padding) behind the end of the previous one
+                const uint64_t ie = hb.in_off[gp] + hb.in_len[gp], oe = hb.out_off[gp] + hb.out_cap[gp];
+                if (hb.in_off[g] < ie || hb.in_off[g] - ie > 15) in_direct = false;
+                if (hb.out_off[g] < oe || hb.out_off[g] - oe > 15) out_direct = false;
+            }
+            budget += need;
+            in_sum += ((uint64_t)hb.in_len[g] + 3u) & ~3ull;
+            out_sum += ((uint64_t)hb.out_cap[g] + 15u) & ~15ull;
             j++;
         }
-        Lane &ln = lanes[turn];
+        Pipe &pp = *pipes[turn];
         turn ^= 1;
-        if (!collect(ln)) {
+        if (!collect(pp)) {
             rc = CHIP_E_LAUNCH;
             break;
         }
-        const uint64_t in_base_lo = in_lo & ~3ull;  // keep the units' alignment relative to a dword-aligned device base
-        const size_t in_span = (size_t)(in_hi - in_base_lo), out_span = (size_t)(o_hi - o_lo), m = j - i;
-        if (!reserve(ln, ((in_span + 3) & ~(size_t)3) + 16, out_span + 16, m)) {
+        const size_t m = j - k, g0 = hb.unit(k), gl = hb.unit(j - 1);
+        const uint64_t in_lo = hb.in_off[g0] & ~3ull;  // a direct slice keeps the units' alignment relative to a dword-aligned base
+        const uint64_t in_span = in_direct ? hb.in_off[gl] + hb.in_len[gl] - in_lo : in_sum;
+        const uint64_t o_lo = hb.out_off[g0];
+        const uint64_t out_span = out_direct ? hb.out_off[gl] + hb.out_cap[gl] - o_lo : out_sum;
+        bool ok = grow_dev(pp.d_in, pp.in_cap, (size_t)((in_span + 3) & ~3ull) + 16) && grow_dev(pp.d_out, pp.out_cap, (size_t)out_span + 16);
+        if (ok && m > pp.arr_units) {
+            chip_device_free(pp.d_arr);
+            chip_pinned_free(pp.h_arr);
+            pp.arr_units = m + (m >> 2) + 64;
+            pp.d_arr = (uint8_t *)chip_device_alloc(arr_bytes(pp.arr_units));
+            pp.h_arr = (uint8_t *)chip_pinned_alloc(arr_bytes(pp.arr_units));
+            ok = pp.d_arr && pp.h_arr;
+            if (!ok) pp.arr_units = 0;
+        }
+        if (ok && !in_direct) ok = grow_pinned(pp.h_in, pp.h_in_cap, (size_t)in_span + 16);
+        if (!ok) {
             rc = CHIP_E_NOMEM;
             break;
         }
-        // per-unit arrays rebased to the slice
-        uint64_t *h_in_off = (uint64_t *)ln.h_arr, *h_out_off = h_in_off + m;
+        // per-unit arrays rebased to the slice (and, for a packed slice, the input bytes gathered)
+        uint64_t *h_in_off = (uint64_t *)pp.h_arr, *h_out_off = h_in_off + m;
         uint32_t *h_in_len = (uint32_t *)(h_out_off + m), *h_out_cap = h_in_len + m;
+        uint64_t ip = 0, op = 0;
         for (size_t u = 0; u < m; u++) {
-            h_in_off[u] = in_off[i + u] - in_base_lo;
-            h_out_off[u] = out_off[i + u] - o_lo;
-            h_in_len[u] = in_len[i + u];
-            h_out_cap[u] = out_cap[i + u];
+            const size_t g = hb.unit(k + u);
+            h_in_len[u] = hb.in_len[g];
+            h_out_cap[u] = hb.out_cap[g];
+            if (in_direct) {
+                h_in_off[u] = hb.in_off[g] - in_lo;
+            } else {
+                h_in_off[u] = ip;
+                memcpy(pp.h_in + ip, hb.in_base + hb.in_off[g], hb.in_len[g]);
+                ip += ((uint64_t)hb.in_len[g] + 3u) & ~3ull;
+            }
+            if (out_direct) {
+                h_out_off[u] = hb.out_off[g] - o_lo;
+            } else {
+                h_out_off[u] = op;
+                op += ((uint64_t)hb.out_cap[g] + 15u) & ~15ull;
+            }
         }
-        uint64_t *d_in_off = (uint64_t *)ln.d_arr, *d_out_off = d_in_off + m;
+        uint64_t *d_in_off = (uint64_t *)pp.d_arr, *d_out_off = d_in_off + m;
         uint32_t *d_in_len = (uint32_t *)(d_out_off + m), *d_out_cap = d_in_len + m, *d_res = d_out_cap + m;
-        bool ok = hipMemcpyAsync(ln.d_arr, ln.h_arr, m * 24, hipMemcpyHostToDevice, ln.stream) == hipSuccess;
-        ok = ok && hipMemcpyAsync(ln.d_in, (const uint8_t *)in_base + in_base_lo, in_span, hipMemcpyHostToDevice, ln.stream) == hipSuccess;
-        ok = ok && launch(m, ln.d_in, d_in_off, d_in_len, ln.d_out, d_out_off, d_out_cap, d_res, d_res + m, (int32_t *)(d_res + 2 * m), ln.stream) == CHIP_OK;
-        ok = ok && hipMemcpyAsync((uint8_t *)out_base + o_lo, ln.d_out, out_span, hipMemcpyDeviceToHost, ln.stream) == hipSuccess;
-        ok = ok && hipMemcpyAsync(ln.h_arr + m * 24, d_res, m * 12, hipMemcpyDeviceToHost, ln.stream) == hipSuccess;
+        ok = hipMemcpyAsync(pp.d_arr, pp.h_arr, m * 24, hipMemcpyHostToDevice, pp.stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(pp.d_in, in_direct ? hb.in_base + in_lo : pp.h_in, (size_t)in_span, hipMemcpyHostToDevice, pp.stream) == hipSuccess;
+        ok = ok && launch(m, pp.d_in, d_in_off, d_in_len, pp.d_out, d_out_off, d_out_cap, d_res, d_res + m, (int32_t *)(d_res + 2 * m), pp.stream) == CHIP_OK;
+        ok = ok && hipMemcpyAsync(pp.h_arr + m * 24, d_res, m * 12, hipMemcpyDeviceToHost, pp.stream) == hipSuccess;
         if (!ok) {
             rc = CHIP_E_LAUNCH;
             break;
         }
-        ln.i0 = i;
-        ln.i1 = j;
-        i = j;
+        pp.k0 = k;
+        pp.k1 = j;
+        pp.out_direct = out_direct;
+        pp.o_lo = o_lo;
+        k = j;
     }
-    for (int k = 0; k < 2; k++) {
-        Lane &ln = lanes[k];
-        if (ln.stream) {
-            if (rc == CHIP_OK) {
-                if (!collect(ln)) rc = CHIP_E_LAUNCH;
-            } else {
-                (void)hipStreamSynchronize(ln.stream);
-            }
+    for (Pipe *p : pipes) {
+        if (rc == CHIP_OK) {
+            if (!collect(*p)) rc = CHIP_E_LAUNCH;
+        } else {
+            (void)hipStreamSynchronize(p->stream);
         }
-    }
-    for (int k = 0; k < 2; k++) {
-        Lane &ln = lanes[k];
-        if (ln.stream) {
-            chip::release_inflate_scratch_of(ln.stream);  // the stream's token scratch goes with it
-            (void)hipStreamDestroy(ln.stream);
-        }
-        chip_device_free(ln.d_in);
-        chip_device_free(ln.d_out);
-        chip_device_free(ln.d_arr);
-        chip_pinned_free(ln.h_arr);
+        pipe_put(p);
     }
     return rc;
 }
+
+bool host_args_ok(size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len, void *out_base, const uint64_t *out_off,
+                  const uint32_t *out_cap, uint32_t *out_len, int32_t *status)
+{
+    return n <= 0x7fffffffull && in_base && in_off && in_len && out_base && out_off && out_cap && out_len && status;
+}
+
 }  // namespace
 
 extern "C" {
@@ -289,19 +477,134 @@ int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint
                            void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
                            uint32_t *in_used, int32_t *status, int device, size_t slice_bytes)
 {
-    if (!in_used) return CHIP_E_INVALID;
-    return host_pipeline(n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, in_used, status, device, slice_bytes,
-                         [=](size_t m, const void *di, const uint64_t *dio, const uint32_t *dil, void *dout, const uint64_t *doo,
-                             const uint32_t *doc, uint32_t *dol, uint32_t *diu, int32_t *dst, void *st) {
-                             return chip_decode_batch(format, m, di, dio, dil, dout, doo, doc, dol, diu, dst, st);
-                         });
+    const int dev1[1] = {device};
+    return chip_decode_batch_multi(format, n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, in_used, status, dev1, 1,
+                                   slice_bytes);
+}
+
+// Contiguous ranges of `list` (unit indices; null = identity) for `parts` workers, balanced by input + output bytes.
+static void balanced_cuts(const uint32_t *list, size_t count, const uint32_t *in_len, const uint32_t *out_cap, int parts, size_t *cuts)
+{
+    uint64_t total = 0;
+    for (size_t k = 0; k < count; k++) {
+        const size_t g = list ? list[k] : k;
+        total += (uint64_t)in_len[g] + out_cap[g] + 64;
+    }
+    uint64_t acc = 0;
+    int next = 1;
+    cuts[0] = 0;
+    for (size_t k = 0; k < count && next < parts; k++) {
+        const size_t g = list ? list[k] : k;
+        acc += (uint64_t)in_len[g] + out_cap[g] + 64;
+        while (next < parts && acc * (uint64_t)parts >= total * (uint64_t)next) cuts[next++] = k + 1;
+    }
+    while (next <= parts) cuts[next++] = count;
+}
+
+int chip_partition_units(size_t n, const uint32_t *in_len, const uint32_t *out_cap, int parts, size_t *cuts)
+{
+    if (parts <= 0 || !cuts || (n && (!in_len || !out_cap))) return CHIP_E_INVALID;
+    balanced_cuts(nullptr, n, in_len, out_cap, parts, cuts);
+    return CHIP_OK;
+}
+
+int chip_decode_batch_multi(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len, void *out_base,
+                            const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, uint32_t *in_used, int32_t *status,
+                            const int *devices, int n_devices, size_t slice_bytes)
+{
+    if (n == 0) return CHIP_OK;
+    if (!host_args_ok(n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status) || !in_used) return CHIP_E_INVALID;
+    switch (format) {
+    case CHIP_FMT_DEFLATE: case CHIP_FMT_ZLIB: case CHIP_FMT_GZIP: case CHIP_FMT_AUTO: case CHIP_FMT_ZSTD: case CHIP_FMT_DETECT: break;
+    default: return CHIP_E_INVALID;
+    }
+    const int visible = chip_device_count();
+    if (visible <= 0) return CHIP_E_NO_DEVICE;
+    std::vector<int> devs;
+    if (!devices || n_devices <= 0) {
+        for (int d = 0; d < visible; d++) devs.push_back(d);
+    } else {
+        for (int k = 0; k < n_devices; k++) {
+            int d = devices[k];
+            if (d < 0 && hipGetDevice(&d) != hipSuccess) return CHIP_E_NO_DEVICE;
+            if (d >= visible) return CHIP_E_INVALID;
+            devs.push_back(d);
+        }
+    }
+    const int parts = (int)devs.size();
+    // per format one list of units (a mixed batch is bucketed by Detection::detect so that every launch is homogeneous)
+    struct Bucket { int format; std::vector<uint32_t> list; bool all; };
+    std::vector<Bucket> buckets;
+    if (format == CHIP_FMT_DETECT) {
+        Bucket bi{CHIP_FMT_AUTO, {}, false}, bz{CHIP_FMT_ZSTD, {}, false};
+        for (size_t i = 0; i < n; i++) {
+            const int kind = chip_detect((const uint8_t *)in_base + in_off[i], in_len[i]);
+            if (kind == CHIP_DETECT_GZIP || kind == CHIP_DETECT_ZLIB) bi.list.push_back((uint32_t)i);
+            else if (kind == CHIP_DETECT_ZSTD) bz.list.push_back((uint32_t)i);
+            else {
+                out_len[i] = 0;
+                in_used[i] = 0;
+                status[i] = kind == CHIP_DETECT_NONE ? CHIP_NEED_INPUT : CHIP_UNKNOWN_FORMAT;
+            }
+        }
+        if (!bi.list.empty()) buckets.push_back(std::move(bi));
+        if (!bz.list.empty()) buckets.push_back(std::move(bz));
+    } else {
+        buckets.push_back(Bucket{format, {}, true});
+    }
+    std::vector<std::vector<size_t>> cuts(buckets.size(), std::vector<size_t>((size_t)parts + 1));
+    for (size_t b = 0; b < buckets.size(); b++)
+        balanced_cuts(buckets[b].all ? nullptr : buckets[b].list.data(), buckets[b].all ? n : buckets[b].list.size(), in_len, out_cap, parts,
+                      cuts[b].data());
+    std::vector<int> rcs((size_t)parts, CHIP_OK);
+    auto worker = [&](int w) {
+        DeviceGuard g(devs[(size_t)w]);
+        if (!g.ok) {
+            rcs[(size_t)w] = CHIP_E_NO_DEVICE;
+            return;
+        }
+        for (size_t b = 0; b < buckets.size() && rcs[(size_t)w] == CHIP_OK; b++) {
+            const size_t lo = cuts[b][(size_t)w], hi = cuts[b][(size_t)w + 1];
+            if (hi == lo) continue;
+            const int fmt = buckets[b].format;
+            // a worker's share of an unselected batch is the index range [lo, hi): express it by shifted array pointers
+            HostBatch hb{(const uint8_t *)in_base, in_off, in_len, (uint8_t *)out_base, out_off, out_cap, out_len, in_used, status, nullptr, hi - lo};
+            if (buckets[b].all) {
+                hb.in_off += lo; hb.in_len += lo; hb.out_off += lo; hb.out_cap += lo; hb.out_len += lo; hb.in_used += lo; hb.status += lo;
+            } else {
+                hb.sel = buckets[b].list.data() + lo;
+            }
+            rcs[(size_t)w] = host_pipeline(hb, devs[(size_t)w], slice_bytes,
+                                           [=](size_t m, const void *di, const uint64_t *dio, const uint32_t *dil, void *dout, const uint64_t *doo,
+                                               const uint32_t *doc, uint32_t *dol, uint32_t *diu, int32_t *dst, void *st) {
+                                               return chip_decode_batch(fmt, m, di, dio, dil, dout, doo, doc, dol, diu, dst, st);
+                                           });
+        }
+    };
+    if (parts == 1) {
+        worker(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int w = 0; w < parts; w++) th.emplace_back(worker, w);  // one host thread per GPU: hipSetDevice is per thread
+        for (auto &t : th) t.join();
+    }
+    for (int rc : rcs)
+        if (rc != CHIP_OK) return rc;
+    return CHIP_OK;
 }
 
 int chip_encode_batch_host(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
                            void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
                            int device, size_t slice_bytes)
 {
-    return host_pipeline(n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, nullptr, status, device, slice_bytes,
+    if (n == 0) return CHIP_OK;
+    if (!host_args_ok(n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status)) return CHIP_E_INVALID;
+    if (!device_ok()) return CHIP_E_NO_DEVICE;
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) return CHIP_E_NO_DEVICE;
+    DeviceGuard g(device);
+    if (!g.ok) return CHIP_E_INVALID;
+    HostBatch hb{(const uint8_t *)in_base, in_off, in_len, (uint8_t *)out_base, out_off, out_cap, out_len, nullptr, status, nullptr, n};
+    return host_pipeline(hb, device, slice_bytes,
                          [=](size_t m, const void *di, const uint64_t *dio, const uint32_t *dil, void *dout, const uint64_t *doo,
                              const uint32_t *doc, uint32_t *dol, uint32_t *, int32_t *dst, void *st) {
                              return chip_encode_batch(format, level, m, di, dio, dil, dout, doo, doc, dol, dst, st);
@@ -472,6 +775,8 @@ bool dec_run(chip_decoder *d)
         a.n = 1;
         a.format = d->format;
         a.stats = nullptr;
+        a.sel = nullptr;
+        a.sel_n = nullptr;
         a.resume = inflate ? d->d_meta->resume : d->d_zres;
         hipError_t e = inflate ? launch_inflate(a, d->stream) : launch_zstd_decode(a, d->window_log_max, d->stream);
         if (e != hipSuccess) return false;
@@ -671,6 +976,8 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
     a.format = format;
     a.stats = nullptr;
     a.resume = nullptr;
+    a.sel = nullptr;
+    a.sel_n = nullptr;
     hipError_t e = launch_deflate_l1(a, level, 7u, format == CHIP_FMT_ZLIB ? 1u : 0u, 0, nullptr, (hipStream_t)stream);
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
@@ -764,6 +1071,8 @@ bool enc_segment(chip_encoder *e, bool final)
     a.format = e->mode;
     a.stats = nullptr;
     a.resume = nullptr;
+    a.sel = nullptr;
+    a.sel_n = nullptr;
     const uint32_t flags = (e->started ? 0u : 1u) | (final ? 2u | 4u : 0u);
     if (launch_deflate_l1(a, e->level, flags, e->check, e->total_in, &e->d_meta->check, e->stream) != hipSuccess) return false;
     if (hipMemcpyAsync(e->h_meta, e->d_meta, sizeof m, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return false;

@@ -41,6 +41,10 @@ struct BatchArgs {
     // block boundary reached (0 = start from the beginning), output bytes produced up to there, wrapper kind.
     // A later call over the same (longer) input and the same output buffer continues from that boundary.
     uint32_t *resume;
+    // Routed batches (CHIP_FMT_DETECT): the kernel works on units sel[0 .. *sel_n) instead of 0 .. n (both device
+    // pointers, written by route_kernel earlier on the same stream); nullptr = all n units in index order.
+    const uint32_t *sel = nullptr;
+    const uint32_t *sel_n = nullptr;
 };
 
 // launchers (each only enqueues on `stream`)
@@ -48,6 +52,11 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);
 hipError_t release_inflate_scratch();  // frees the cached token scratch of the current device (after a device sync)
 void release_inflate_scratch_of(hipStream_t stream);  // the same for one (drained) stream of the current device
 hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_t stream);
+// Detection-driven router of a mixed batch: appends the index of every gzip / zlib unit to sel_inflate and of every zstd
+// frame to sel_zstd (counts[0], counts[1], zeroed by the call) and answers units that are neither at once.
+hipError_t launch_route(const BatchArgs &a, uint32_t *sel_inflate, uint32_t *sel_zstd, uint32_t *counts, hipStream_t stream);
+// device scratch of a routed batch on `stream`, cached with the inflate slot: two index lists of n entries + 2 counters
+hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts);
 hipError_t launch_detect(size_t n, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
                          hipStream_t stream);
 hipError_t launch_deflate_l1(const BatchArgs &a, int level, uint32_t flags, uint32_t check_seed, uint64_t total_before,

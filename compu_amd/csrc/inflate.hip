@@ -1025,19 +1025,6 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     STAT_T0();
     uint32_t wrap = 0;
     int32_t format = a.format;
-    if (format == CHIP_FMT_DETECT) {
-        const int32_t kind = (int32_t)rdfirst((uint32_t)detect_kind(gin, in_len));
-        if (kind == CHIP_DETECT_ZSTD) return;  // the zstd kernel of the same batch call owns this unit
-        if (kind == CHIP_DETECT_GZIP || kind == CHIP_DETECT_ZLIB) format = CHIP_FMT_AUTO;
-        else {
-            if (lane == 0) {
-                a.out_len[u] = 0;
-                a.in_used[u] = 0;
-                a.status[u] = kind == CHIP_DETECT_NONE ? CHIP_NEED_INPUT : CHIP_UNKNOWN_FORMAT;
-            }
-            return;
-        }
-    }
     uint32_t ck_bit = 0, ck_opos = 0;  // last block boundary reached (streaming decoder: where the next call resumes)
     bool resumed = false;
     if (a.resume) {
@@ -1278,11 +1265,13 @@ __global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchA
 {
     __shared__ WaveLds L;
     uint32_t *grow = scratch + (size_t)blockIdx.x * SCRATCH_WORDS_PER_WAVE;
+    const uint32_t limit = a.sel_n ? *a.sel_n : a.n;
     for (;;) {
-        uint32_t u = 0;
-        if (lane_id() == 0) u = atomicAdd(next_unit, 1u);
-        u = rdfirst(u);
-        if (u >= a.n) break;
+        uint32_t i = 0;
+        if (lane_id() == 0) i = atomicAdd(next_unit, 1u);
+        i = rdfirst(i);
+        if (i >= limit) break;
+        const uint32_t u = a.sel ? rdfirst(a.sel[i]) : i;
         inflate_unit(a, u, L, grow);
         WSYNC();  // the next unit reuses the LDS
     }
@@ -1295,23 +1284,38 @@ struct LaunchSlot {
     uint32_t *scratch = nullptr;
     uint32_t *counter = nullptr;
     int blocks = 0;
+    uint32_t *route = nullptr;  // routed batches: [0,1] list lengths, then two index lists of route_cap entries
+    size_t route_cap = 0;
 };
 std::mutex g_slot_mu;
 std::map<std::pair<int, hipStream_t>, LaunchSlot> g_slots;
 
-hipError_t slot_for(hipStream_t stream, LaunchSlot &out)
+// The slot of (current device, stream), with token scratch for min(n, resident waves) waves: a streaming decoder
+// (batches of one) holds 48 KiB, not the 200 MB a full grid needs; the scratch grows when a larger batch arrives.
+hipError_t slot_for(hipStream_t stream, uint32_t n, LaunchSlot &out)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
     std::lock_guard<std::mutex> lk(g_slot_mu);
     LaunchSlot &sl = g_slots[{dev, stream}];
-    if (!sl.scratch) {
+    static int max_blocks[64] = {0};  // resident waves of a full grid, per device
+    const int di = dev < 64 ? dev : 63;
+    if (!max_blocks[di]) {
         int per_cu = 0, cus = 0;
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inflate_kernel, 64, 0)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
-        const int blocks = per_cu * cus;
+        max_blocks[di] = per_cu * cus;
+    }
+    const int want = n < (uint32_t)max_blocks[di] ? (int)n : max_blocks[di];
+    if (sl.blocks < want) {
+        if (sl.scratch && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // launches on the stream still use it
+        (void)hipFree(sl.scratch);
+        sl.scratch = nullptr;
+        sl.blocks = 0;
+        // a little headroom for batches that grow slowly (streaming objects stay at one wave)
+        const int blocks = want <= 1 ? 1 : (want + want / 4 < max_blocks[di] ? want + want / 4 : max_blocks[di]);
         uint32_t *p = nullptr;
         if ((e = hipMalloc((void **)&p, (size_t)blocks * SCRATCH_WORDS_PER_WAVE * 4 + 256)) != hipSuccess) return e;
         sl.scratch = p;
@@ -1323,6 +1327,29 @@ hipError_t slot_for(hipStream_t stream, LaunchSlot &out)
 }
 }  // namespace
 
+hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    LaunchSlot &sl = g_slots[{dev, stream}];
+    if (n > sl.route_cap) {
+        // work queued on the stream may still read the old lists: let it finish before they go
+        if (sl.route && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        (void)hipFree(sl.route);
+        sl.route = nullptr;
+        sl.route_cap = 0;
+        const size_t cap = n + (n >> 2) + 1024;
+        if ((e = hipMalloc((void **)&sl.route, (2 * cap + 4) * 4)) != hipSuccess) return e;
+        sl.route_cap = cap;
+    }
+    *counts = sl.route;
+    *sel_inflate = sl.route + 4;
+    *sel_zstd = sl.route + 4 + sl.route_cap;
+    return hipSuccess;
+}
+
 hipError_t release_inflate_scratch()
 {
     int dev = 0;
@@ -1333,6 +1360,7 @@ hipError_t release_inflate_scratch()
     for (auto it = g_slots.begin(); it != g_slots.end();) {
         if (it->first.first == dev) {
             (void)hipFree(it->second.scratch);
+            (void)hipFree(it->second.route);
             it = g_slots.erase(it);
         } else {
             ++it;
@@ -1349,6 +1377,7 @@ void release_inflate_scratch_of(hipStream_t stream)
     auto it = g_slots.find({dev, stream});
     if (it != g_slots.end()) {
         (void)hipFree(it->second.scratch);
+        (void)hipFree(it->second.route);
         g_slots.erase(it);
     }
 }
@@ -1357,7 +1386,7 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
     LaunchSlot sl;
-    hipError_t e = slot_for(stream, sl);
+    hipError_t e = slot_for(stream, a.n, sl);
     if (e != hipSuccess) return e;
     // counter reset and kernel must reach the stream back to back even when several host threads launch on it
     static std::mutex enqueue_mu;

@@ -748,14 +748,13 @@ __device__ void wave_match_copy(uint8_t *dst, uint32_t offset, uint32_t n)
 __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, int wlog_max)
 {
     __shared__ ZLds L;
-    const uint32_t u = blockIdx.x;
-    if (u >= a.n) return;
+    if (blockIdx.x >= (a.sel_n ? *a.sel_n : a.n)) return;
+    const uint32_t u = a.sel ? a.sel[blockIdx.x] : blockIdx.x;
     const uint32_t lane = lane_id();
     const uint8_t *gin = a.in_base + a.in_off[u];
     const uint32_t in_len = a.in_len[u];
     uint8_t *gout = a.out_base + a.out_off[u];
     const uint32_t cap = a.out_cap[u];
-    if (a.format == CHIP_FMT_DETECT && detect_kind(gin, in_len) != CHIP_DETECT_ZSTD) return;  // the inflate kernel's unit
 
     Bits b;
     const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);

@@ -20,6 +20,25 @@ def weak_shard(units_per_gpu, rank):
     return rank * units_per_gpu, units_per_gpu
 
 
+def partition_units(in_len, out_cap, parts):
+    """The library's host-side partition of a batch over `parts` GPUs (chip_partition_units): contiguous unit ranges
+    balanced by input + output bytes; returns the parts + 1 cut positions."""
+    import ctypes as C
+
+    import numpy as np
+
+    from . import api
+
+    in_len = np.ascontiguousarray(in_len, dtype=np.uint32)
+    out_cap = np.ascontiguousarray(out_cap, dtype=np.uint32)
+    cuts = np.zeros(parts + 1, dtype=np.uint64)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rc = api.lib().chip_partition_units(len(in_len), p(in_len), p(out_cap), int(parts), p(cuts))
+    if rc != 0:
+        raise ValueError(f"chip_partition_units failed: {rc}")
+    return [int(c) for c in cuts]
+
+
 def timed_region(fn, steps, dist=None, sync=None, device=None):
     """Run fn() `steps` times between barriers; returns the max-over-ranks wall time in seconds.
     `sync` is called before the clock starts and before it stops (torch.cuda.synchronize on the GPU box)."""

@@ -150,17 +150,38 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
 /*
  * The same for data that starts and ends in HOST memory (SURVEY.md sec. 8b "pinned-host variant", 8e): every
  * pointer is a host pointer (hipHostMalloc / chip_pinned_alloc memory lets the copies run asynchronously; pageable
- * memory works but serialises them).  The units are cut into slices of consecutive indices (about `slice_bytes` of
- * input + output each, 0 = 256 MiB); slices alternate between two HIP streams, each running H2D -> kernel -> D2H for
- * its slice, so the copies of one slice overlap the kernel of the other.  Offsets are relative to in_base /
- * out_base as in chip_decode_batch; a slice copies the byte range its units span, so units packed in index order
- * (the usual layout) move no extra bytes; the host output range of a slice is written as a whole, so bytes between
- * out_len[i] and out_cap[i] end up unspecified.  Returns when everything has arrived in host memory.
+ * memory works but serialises them).  The units are cut into slices (about `slice_bytes` of input + output each,
+ * 0 = 256 MiB); slices alternate between two HIP streams, each running H2D -> kernel -> D2H for its slice, so the
+ * copies of one slice overlap the kernel of the other.  Offsets are relative to in_base / out_base as in
+ * chip_decode_batch.  A slice whose units lie back to back in index order (the usual layout; up to 15 bytes of
+ * padding between units) moves straight between the caller's memory and the device; any other layout (gaps, reverse
+ * order, overlapping ranges) is packed through pinned staging buffers.  Exactly out_len[i] bytes are written at
+ * out_off[i]; nothing else in out_base is touched.  Returns when everything has arrived in host memory; the
+ * calling thread's current device is left as it was.  Streams and buffers are kept per device between calls
+ * (chip_trim() releases them).
  * No reference counterpart: compu's decode loop is the host-memory path (src/decoder/mod.rs:323-335).
  */
 int chip_decode_batch_host(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
                            void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
                            uint32_t *in_used, int32_t *status, int device, size_t slice_bytes);
+
+/*
+ * chip_decode_batch_host over several GPUs of the node (independent units, no exchange step, no
+ * collective).  `devices[0 .. n_devices)` are HIP device ordinals (NULL / 0 = every visible device).  The units are
+ * partitioned on the host into one contiguous index range per device, balanced by input + output bytes; a
+ * CHIP_FMT_DETECT batch is first bucketed by Detection::detect (src/decoder/mod.rs:28-114) so that every launch is
+ * homogeneous (gzip/zlib units to the inflate kernel, zstd frames to the zstd kernel; units that are neither are
+ * answered on the host).  Each device is driven by a host thread of its own (hipSetDevice is per thread) with two
+ * streams, as above; results land in the caller's per-unit arrays.  Returns the first failure of any device.
+ */
+int chip_decode_batch_multi(int format, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                            void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                            uint32_t *in_used, int32_t *status, const int *devices, int n_devices, size_t slice_bytes);
+
+/* The host-side partition chip_decode_batch_multi uses: cuts[0 .. parts] with cuts[0] = 0 and
+ * cuts[parts] = n; worker w owns units [cuts[w], cuts[w+1]), contiguous and balanced by in_len + out_cap bytes.
+ * Pure host arithmetic (no device needed). */
+int chip_partition_units(size_t n, const uint32_t *in_len, const uint32_t *out_cap, int parts, size_t *cuts);
 
 /* Detection::detect src/decoder/mod.rs:28-114 on the first bytes of each unit; kind[i] gets a
  * CHIP_DETECT_* value.  Host form and batched device form. */
@@ -199,8 +220,8 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
 /* Worst-case compressed size for in_len input bytes in `format` (sizing out_cap). */
 size_t chip_encode_bound(int format, size_t in_len);
 
-/* chip_encode_batch for data in (pinned) host memory: same two-stream slicing as chip_decode_batch_host; the host
- * output range of a slice is written as a whole (bytes between out_len[i] and out_cap[i] end up unspecified). */
+/* chip_encode_batch for data in (pinned) host memory: same two-stream slicing and layout rules as
+ * chip_decode_batch_host (exactly out_len[i] bytes are written at out_off[i]). */
 int chip_encode_batch_host(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
                            void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
                            int device, size_t slice_bytes);

@@ -261,6 +261,111 @@ def test_host_memory_variant_matches_device_variant(gpu, alice):
             assert outs_d[i] == datas[i]
 
 
+def test_host_batch_layouts_reverse_order_gaps_and_poison(gpu, alice):
+    """chip_decode_batch_host with layouts the straight-through path cannot serve: output ranges in REVERSE unit order,
+    gaps between units, short outputs.  Exactly out_len bytes are written per unit; every other byte of the caller's
+    output keeps its poison (a slice used to be copied back as one span of uninitialised device memory)."""
+    import compu_amd
+
+    rnd = random.Random(9)
+    datas, parts = [], []
+    for it in range(120):
+        n = rnd.choice([0, 10, 700, 5000, 40000, 65536])
+        data = _mk(rnd.randrange(5), n, rnd, alice)
+        co = zlib.compressobj(rnd.choice([1, 6]), zlib.DEFLATED, -15)
+        datas.append(data)
+        parts.append(co.compress(data) + co.flush())
+    parts[7] = parts[7][: len(parts[7]) // 2]  # a truncated unit writes what it decoded and nothing more
+    buf, offs, lens = _pack(parts)
+    caps = np.array([len(d) + rnd.choice([0, 0, 33, 1000]) for d in datas], dtype=np.uint32)
+    caps[11] = len(datas[11]) // 2  # too small: NeedOutput with exactly cap bytes
+    gaps = np.array([rnd.choice([16, 48, 64, 1000]) for _ in datas], dtype=np.uint64)
+    spans = ((caps.astype(np.uint64) + 15) & ~np.uint64(15)) + gaps
+    for order in ("reverse", "forward"):
+        ooff = np.zeros(len(parts), dtype=np.uint64)
+        if order == "reverse":
+            ooff[::-1][1:] = np.cumsum(spans[::-1][:-1])
+        else:
+            ooff[1:] = np.cumsum(spans[:-1])
+        out = np.full(int(spans.sum()) + 64, 0xA5, np.uint8)
+        ol, iu, st = compu_amd.decode_batch_host(-15, buf, offs.astype(np.uint64), lens.astype(np.uint32), out, ooff, caps, slice_bytes=300_000)
+        ref = oracle_batch(-15, parts, caps)
+        mask = np.ones(len(out), bool)
+        for i in range(len(parts)):
+            got = bytes(out[int(ooff[i]) : int(ooff[i]) + int(ol[i])])
+            assert got == ref[i][0] and st[i] == ref[i][2], (order, i, st[i], ref[i][2])
+            mask[int(ooff[i]) : int(ooff[i]) + int(ol[i])] = False
+        assert (out[mask] == 0xA5).all(), f"{order}: bytes outside the produced ranges were written"
+        assert st[7] == 0 and st[11] == 1 and ol[11] == caps[11]
+
+
+def test_multi_device_entry_buckets_by_format(gpu, alice):
+    """chip_decode_batch_multi: the host-side partition of SURVEY.md sec. 8e.  Two workers (both on device 0 here: a
+    one-GPU box) take contiguous, byte-balanced unit ranges; a CHIP_FMT_DETECT batch is bucketed so that every launch is
+    homogeneous (units interleave gzip / zlib / zstd / garbage / too-short).  Same results as the one-launch device path."""
+    import compu_amd
+    import zstd_ref
+
+    rnd = random.Random(21)
+    z = zstd_ref.load()
+    datas, parts = [], []
+    for it in range(300):
+        n = rnd.choice([0, 300, 9000, 65536])
+        data = _mk(rnd.randrange(5), n, rnd, alice)
+        k = rnd.randrange(5)
+        if k == 0:
+            comp = zlib.compress(data, 6)
+        elif k == 1:
+            co = zlib.compressobj(6, zlib.DEFLATED, 31)
+            comp = co.compress(data) + co.flush()
+        elif k == 2:
+            comp = zstd_ref.compress(z, data, 3)
+        elif k == 3:
+            comp = bytes(rnd.randrange(1, 255) for _ in range(rnd.randrange(4, 40)))  # Detection::Unknown (mostly)
+        else:
+            comp = b"\x1f"  # too short to classify
+        datas.append(data)
+        parts.append(comp)
+    caps = [len(d) + 64 for d in datas]
+    outs_d, ol_d, iu_d, st_d = run_batch(gpu, 0, parts, caps, check_tail=False)
+    buf, offs, lens = _pack(parts)
+    caps_a = np.asarray(caps, dtype=np.uint32)
+    ooff = np.zeros(len(parts), dtype=np.uint64)
+    ooff[1:] = np.cumsum(((caps_a[:-1].astype(np.uint64) + 15) & ~np.uint64(15)))
+    for devices in ([0], [0, 0], None):
+        out = np.full(int(ooff[-1] + caps_a[-1]) + 16, 0x5A, np.uint8)
+        ol, iu, st = compu_amd.decode_batch_multi(0, buf, offs.astype(np.uint64), lens.astype(np.uint32), out, ooff, caps_a, devices=devices,
+                                                  slice_bytes=1 << 20)
+        assert (st == st_d).all() and (ol == ol_d).all() and (iu == iu_d).all(), devices
+        for i in range(len(parts)):
+            assert bytes(out[int(ooff[i]) : int(ooff[i]) + int(ol[i])]) == outs_d[i], (devices, i)
+    assert set(np.unique(st_d).tolist()) >= {0, 2, 4}  # finished units, too-short (NeedInput) and Unknown ones all occur
+    with pytest.raises(RuntimeError):
+        compu_amd.decode_batch_multi(0, buf, offs, lens, out, ooff, caps_a, devices=[0, 99])  # no such device: refused, not ignored
+
+
+def test_detect_batch_matches_host_detection(gpu):
+    """chip_detect_batch (device) == chip_detect (host) == Detection::detect (src/decoder/mod.rs:28-114), every 2-byte
+    prefix that can matter plus the zstd magic and short inputs."""
+    import compu_amd
+
+    parts = [b"", b"\x1f", b"\x1f\x8b", b"\x28\xb5\x2f", b"\x28\xb5\x2f\xfd", b"abcd", b"ab", b"\x28\xb5\x2f\xfd\x00\x00"]
+    for cmf in (0x08, 0x18, 0x28, 0x38, 0x48, 0x58, 0x68, 0x78, 0x88):
+        for flg in range(256):
+            parts.append(bytes([cmf, flg]))
+            parts.append(bytes([cmf, flg, 0, 0]))
+    buf, offs, lens = _pack(parts)
+    dev = "cuda:0"
+    kind = compu_amd.detect_batch(gpu.from_numpy(buf).to(dev), gpu.from_numpy(offs).to(dev), gpu.from_numpy(lens).to(dev))
+    gpu.cuda.synchronize()
+    kind = kind.cpu().numpy()
+    L = compu_amd.lib()
+    for i, p in enumerate(parts):
+        assert kind[i] == L.chip_detect(p, len(p)), (i, p, kind[i])
+    with pytest.raises(TypeError):  # int32 offsets would be read as u64 on the device: refused on the host
+        compu_amd.detect_batch(gpu.from_numpy(buf).to(dev), gpu.from_numpy(offs.astype(np.int32)).to(dev), gpu.from_numpy(lens).to(dev))
+
+
 def test_concurrent_launches_from_two_host_threads(gpu):
     """Two host threads launch batches on the same (default) stream at the same time: the persistent kernel's unit
     counter is reset and consumed per launch, so neither batch may lose or repeat units."""

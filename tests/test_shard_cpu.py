@@ -29,6 +29,44 @@ def test_shard_ranges_partition_the_batch():
     assert shard.aggregate_rate(4 << 30, 8, 20, 2.0) == (4 << 30) * 8 * 20 / 2.0
 
 
+def test_library_partition_is_contiguous_and_balanced():
+    """chip_partition_units (the host-side partition of chip_decode_batch_multi): pure host logic."""
+    rnd = np.random.default_rng(5)
+    for n in (0, 1, 5, 1000, 65536):
+        for parts in (1, 2, 4, 8):
+            in_len = rnd.integers(0, 70000, n, dtype=np.uint32)
+            out_cap = rnd.integers(0, 200000, n, dtype=np.uint32)
+            cuts = shard.partition_units(in_len, out_cap, parts)
+            assert len(cuts) == parts + 1 and cuts[0] == 0 and cuts[-1] == n
+            assert all(a <= b for a, b in zip(cuts, cuts[1:]))
+            if n >= 1000:
+                w = in_len.astype(np.int64) + out_cap + 64
+                loads = [int(w[a:b].sum()) for a, b in zip(cuts, cuts[1:])]
+                assert max(loads) - min(loads) <= 2 * int(w.max()), (n, parts, loads)
+    # equal units: equal counts (the benchmark's fixed 64 KiB units)
+    cuts = shard.partition_units(np.full(65536, 33000, np.uint32), np.full(65536, 65536, np.uint32), 8)
+    assert cuts == [8192 * k for k in range(9)]
+    with pytest.raises(ValueError):
+        shard.partition_units([1], [1], 0)
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """`python bench.py --gpus N` without a launcher starts its own ranks; with fewer than N devices visible it must say
+    so and exit non-zero instead of silently measuring fewer GPUs (here: no GPU at all, or one on the GPU box)."""
+    import subprocess
+
+    visible = torch.cuda.device_count()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(visible + 2)], capture_output=True, text=True, env=env, timeout=120)
+    assert out.returncode != 0
+    assert f"--gpus {visible + 2} but only {visible} GPU(s) are visible" in out.stderr
+    assert out.stdout.strip() == ""  # no JSON line that could be mistaken for a measurement
+    # a launcher-provided WORLD_SIZE that disagrees with --gpus is refused as well
+    env2 = dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env2, timeout=120)
+    assert out.returncode != 0 and "must agree" in out.stderr
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
