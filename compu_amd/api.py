@@ -83,6 +83,10 @@ def lib():
     L.chip_decoder_reset.restype = vp
     L.chip_decoder_reset.argtypes = [vp]
     L.chip_decoder_free.argtypes = [vp]
+    L.chip_decoder_footprint.argtypes = [vp, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    L.chip_decoder_footprint.restype = None
+    L.chip_set_allocator.argtypes = [vp, vp, vp]
+    L.chip_set_allocator.restype = None
     L.chip_decoder_strerror.restype = C.c_char_p
     L.chip_decoder_strerror.argtypes = [C.c_int, i32]
     L.chip_decode_batch.restype = C.c_int
@@ -390,6 +394,12 @@ class Decoder:
             self._h = h
             return True
         return False
+
+    def footprint(self):
+        """(pinned host bytes, device bytes) this decoder holds right now (chip_decoder_footprint)."""
+        a, b = C.c_size_t(0), C.c_size_t(0)
+        lib().chip_decoder_footprint(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
 
     # mod.rs:445-447
     def describe_error(self, error):

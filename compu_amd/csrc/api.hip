@@ -22,16 +22,27 @@ using namespace chip;
 
 namespace {
 
-chip_malloc_fn g_malloc = nullptr;
-chip_free_fn g_free = nullptr;
-void *g_opaque = nullptr;
-
-void *host_alloc(size_t n) { return g_malloc ? g_malloc(g_opaque, n) : malloc(n); }
-void host_free(void *p)
+// Host-state allocator hooks (src/mem.rs:52-57,74-76).  chip_set_allocator may be called from any thread; an object
+// keeps the hooks that were installed when it was made, so it is freed by the allocator that allocated it whatever is
+// installed later (separate decoders on separate threads must not share unsynchronised globals).
+struct Hooks {
+    chip_malloc_fn malloc_fn = nullptr;
+    chip_free_fn free_fn = nullptr;
+    void *opaque = nullptr;
+    void *alloc(size_t n) const { return malloc_fn ? malloc_fn(opaque, n) : malloc(n); }
+    void release(void *p) const
+    {
+        if (!p) return;
+        if (free_fn) free_fn(opaque, p);
+        else free(p);
+    }
+};
+std::mutex g_hooks_mu;
+Hooks g_hooks;
+Hooks current_hooks()
 {
-    if (!p) return;
-    if (g_free) g_free(g_opaque, p);
-    else free(p);
+    std::lock_guard<std::mutex> lk(g_hooks_mu);
+    return g_hooks;
 }
 
 bool device_ok()
@@ -45,7 +56,7 @@ struct Meta {
     uint64_t in_off, out_off;
     uint32_t in_len, out_cap, out_len, in_used;
     int32_t status;
-    uint32_t resume[3];  // inflate streaming: see BatchArgs::resume
+    uint32_t resume[RESUME_WORDS];  // inflate streaming: see BatchArgs::resume
 };
 
 void pipes_trim();  // defined with the host-batch pipelines below
@@ -67,9 +78,11 @@ const char *chip_version(void) { return "compu-hip 0.1 (gfx950)"; }
 
 void chip_set_allocator(chip_malloc_fn malloc_fn, chip_free_fn free_fn, void *opaque)
 {
-    g_malloc = malloc_fn;
-    g_free = free_fn;
-    g_opaque = opaque;
+    std::lock_guard<std::mutex> lk(g_hooks_mu);
+    // both or neither: memory from one allocator must never reach the other's free
+    g_hooks.malloc_fn = (malloc_fn && free_fn) ? malloc_fn : nullptr;
+    g_hooks.free_fn = (malloc_fn && free_fn) ? free_fn : nullptr;
+    g_hooks.opaque = (malloc_fn && free_fn) ? opaque : nullptr;
 }
 
 void *chip_device_alloc(size_t size)
@@ -678,6 +691,7 @@ const char *chip_decoder_strerror(int format, int32_t code)
 // ---- streaming decoder -----------------------------------------------------------------------
 
 struct chip_decoder {
+    Hooks hooks;  // the allocator this object came from
     int format;
     int device;
     int window_log_max;
@@ -696,7 +710,9 @@ struct chip_decoder {
     size_t delivered;  // decoded bytes already handed to the caller
     bool done;
     size_t d_in_len;      // input bytes already on the device (the stream only grows)
-    uint32_t resume[3];   // inflate: last block boundary the kernel reached (BatchArgs::resume); zeros = from the start
+    uint32_t resume[RESUME_WORDS];  // inflate: last block boundary the kernel reached, running check (BatchArgs::resume); zeros = from the start
+    size_t in_dropped;    // input bytes dropped in front of the buffer so far
+    uint32_t last_ck;     // resume[0] + 8 * input bytes dropped so far: tells whether a run reached a new block boundary
     uint32_t *d_zres;     // zstd: device blob with the kernel's block checkpoint (header + decode tables), see zstd.hip
 };
 
@@ -716,13 +732,20 @@ bool dec_reserve_in(chip_decoder *d, size_t need)
     return true;
 }
 
+// Limits of a streaming object: the kernels address a unit's input by 32-bit bit offsets and its output
+// by 32-bit byte offsets.  What is BUFFERED stays far below them (input in front of the last block boundary and output
+// that has been handed on are dropped), so only a single deflate block or zstd frame of that size can run into them.
+constexpr size_t DEC_IN_LIMIT = (size_t)256 << 20;    // buffered compressed bytes
+constexpr size_t DEC_OUT_LIMIT = 0xfffffff0ull;       // decoded bytes held on the device
+constexpr size_t DEC_OUT_SOFT = (size_t)8 << 20;      // the device output is not grown past this while the stream makes progress
+constexpr size_t DEC_DROP_IN = 65536, DEC_DROP_OUT = (size_t)1 << 20;  // housekeeping thresholds
+
 // Decode what has accumulated.  Input is appended to the device copy (only the new bytes cross the link), an inflate
-// stream continues from the last block boundary an earlier call reached (the output so far stays on the device: it is the
-// window and what the trailer checksum covers), so feeding a long stream in pieces costs O(stream), not O(stream^2).
-// zstd frames are decoded from their start each time.  The device output grows (contents kept) while it is the limit.
+// stream continues from the last block boundary an earlier call reached (the window in front of it stays on the device,
+// the trailer check is carried as a running value), so feeding a long stream in pieces costs O(stream) time and
+// O(window + piece) memory.  The device output grows while a run reaches no new boundary without it.
 bool dec_run(chip_decoder *d)
 {
-    if (hipSetDevice(d->device) != hipSuccess) return false;
     const size_t in_len = d->h_in_len;
     const size_t need_in = ((in_len + 3) & ~(size_t)3) + 16;
     if (need_in > d->d_in_cap) {
@@ -747,19 +770,21 @@ bool dec_run(chip_decoder *d)
     }
     size_t cap = d->d_out_cap;
     if (cap == 0) cap = in_len * 4 > 65536 ? in_len * 4 : 65536;
+    if (cap > DEC_OUT_SOFT && d->d_out_cap == 0) cap = DEC_OUT_SOFT;
     for (;;) {
-        if (cap > 0xffffffffull) cap = 0xffffffffull;
+        if (cap > DEC_OUT_LIMIT) cap = DEC_OUT_LIMIT;
         if (cap > d->d_out_cap) {
             uint8_t *p = (uint8_t *)chip_device_alloc(cap);
             if (!p) return false;
-            const size_t keep = inflate ? (size_t)d->resume[1] : (size_t)d->k_out_len;  // a stream resumes: its output so far must survive
+            const size_t keep = d->k_out_len;  // the window of a stream that resumes and what has not been delivered yet
             if (keep && hipMemcpyAsync(p, d->d_out, keep, hipMemcpyDeviceToDevice, d->stream) != hipSuccess) return false;
             if (keep && hipStreamSynchronize(d->stream) != hipSuccess) return false;
             chip_device_free(d->d_out);
             d->d_out = p;
             d->d_out_cap = cap;
         }
-        Meta m = {0, 0, (uint32_t)in_len, (uint32_t)d->d_out_cap, 0, 0, 0, {d->resume[0], d->resume[1], d->resume[2]}};
+        Meta m = {0, 0, (uint32_t)in_len, (uint32_t)d->d_out_cap, 0, 0, 0, {0}};
+        for (uint32_t k = 0; k < RESUME_WORDS; k++) m.resume[k] = d->resume[k];
         *d->h_meta = m;
         if (hipMemcpyAsync(d->d_meta, d->h_meta, sizeof(Meta), hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
         BatchArgs a;
@@ -775,26 +800,66 @@ bool dec_run(chip_decoder *d)
         a.n = 1;
         a.format = d->format;
         a.stats = nullptr;
-        a.sel = nullptr;
-        a.sel_n = nullptr;
         a.resume = inflate ? d->d_meta->resume : d->d_zres;
         hipError_t e = inflate ? launch_inflate(a, d->stream) : launch_zstd_decode(a, d->window_log_max, d->stream);
         if (e != hipSuccess) return false;
         if (hipMemcpyAsync(d->h_meta, d->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;
         if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
-        if (inflate)
-            for (int k = 0; k < 3; k++) d->resume[k] = d->h_meta->resume[k];
+        bool progress = true;
+        if (inflate) {
+            for (uint32_t k = 0; k < RESUME_WORDS; k++) d->resume[k] = d->h_meta->resume[k];
+            const uint32_t ck = d->resume[0] + 8u * (uint32_t)d->in_dropped;
+            progress = ck != d->last_ck || d->h_meta->out_len > d->delivered;  // a new block boundary, or bytes to hand on
+            d->last_ck = ck;
+        }
         d->k_out_len = d->h_meta->out_len;
-        if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < 0xffffffffull) {
+        // out of device output: a zstd frame is decoded in one piece (grow); an inflate stream that got somewhere hands
+        // on what it has and continues from its last boundary in a buffer of the same size
+        if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < DEC_OUT_LIMIT && (!inflate || !progress || d->d_out_cap < DEC_OUT_SOFT)) {
             cap = d->d_out_cap * 2;
             continue;
         }
         break;
     }
-    d->k_out_len = d->h_meta->out_len;
     d->k_in_used = d->h_meta->in_used;
     d->k_status = d->h_meta->status;
     d->decoded = true;
+    return true;
+}
+
+// Between calls of an inflate stream that goes on: drop the input in front of the last block boundary and the output in
+// front of the 32 KiB window of that boundary that has been handed on (BatchArgs::resume says how the kernel is told).
+bool dec_compact(chip_decoder *d)
+{
+    if (d->format == CHIP_FMT_ZSTD || !d->decoded) return true;
+    if (d->k_status != CHIP_NEED_INPUT && d->k_status != CHIP_NEED_OUTPUT) return true;
+    const uint32_t r0 = d->resume[0], r1 = d->resume[1];
+    if (r0 == 0) return true;
+    const size_t bnd = r0 >> 3;  // the boundary's byte; 8 bytes stay in front of it so that the offset never becomes 0
+    const size_t drop_in = bnd > 8 ? ((bnd - 8) & ~(size_t)3) : 0;
+    if (drop_in >= DEC_DROP_IN) {
+        memmove(d->h_in, d->h_in + drop_in, d->h_in_len - drop_in);
+        d->h_in_len -= drop_in;
+        d->d_in_len = 0;  // the (short) rest is uploaded again
+        d->resume[0] -= 8u * (uint32_t)drop_in;
+        d->in_dropped += drop_in;
+        d->k_in_used = d->k_in_used > drop_in ? d->k_in_used - (uint32_t)drop_in : 0;
+    }
+    size_t keep_from = d->delivered < r1 ? d->delivered : r1;
+    keep_from = keep_from > 32768 ? ((keep_from - 32768) & ~(size_t)15) : 0;
+    if (keep_from >= DEC_DROP_OUT) {
+        const size_t n = d->k_out_len - keep_from;
+        for (size_t done = 0; done < n;) {  // forward, in pieces no longer than the distance: source and destination never overlap
+            const size_t c = n - done < keep_from ? n - done : keep_from;
+            if (hipMemcpyAsync(d->d_out + done, d->d_out + keep_from + done, c, hipMemcpyDeviceToDevice, d->stream) != hipSuccess) return false;
+            done += c;
+        }
+        if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
+        d->delivered -= keep_from;
+        d->k_out_len -= (uint32_t)keep_from;
+        d->resume[1] -= (uint32_t)keep_from;
+        d->resume[5] += (uint32_t)keep_from;
+    }
     return true;
 }
 
@@ -807,7 +872,9 @@ void dec_clear(chip_decoder *d)
     d->delivered = 0;
     d->done = false;
     d->d_in_len = 0;
-    d->resume[0] = d->resume[1] = d->resume[2] = 0;
+    for (uint32_t k = 0; k < RESUME_WORDS; k++) d->resume[k] = 0;
+    d->last_ck = 0;
+    d->in_dropped = 0;
     if (d->d_zres) {  // the next stream starts from its frame header
         (void)hipMemsetAsync(d->d_zres, 0, 64, d->stream);
         (void)hipStreamSynchronize(d->stream);
@@ -826,15 +893,18 @@ chip_decoder *chip_decoder_new(int format, const chip_decoder_opts *opts)
     if (!device_ok()) return nullptr;  // no CPU codec behind this backend
     int device = opts ? opts->device : -1;
     if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
-    chip_decoder *d = (chip_decoder *)host_alloc(sizeof(chip_decoder));
+    DeviceGuard guard(device);
+    if (!guard.ok) return nullptr;
+    const Hooks hooks = current_hooks();
+    chip_decoder *d = (chip_decoder *)hooks.alloc(sizeof(chip_decoder));
     if (!d) return nullptr;
     memset(d, 0, sizeof *d);
+    d->hooks = hooks;
     d->format = format;
     d->device = device;
     d->window_log_max = opts ? opts->window_log_max : 0;
     if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
-        host_free(d);
+        hooks.release(d);
         return nullptr;
     }
     d->d_meta = (Meta *)chip_device_alloc(sizeof(Meta));
@@ -860,36 +930,47 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
         r.status = CHIP_FINISHED;
         return r;
     }
+    DeviceGuard guard(d->device);  // the caller's current device is put back on return
+    auto fail = [&](int32_t err) {
+        r.status = -1;
+        r.err = err;
+        return r;
+    };
+    if (!guard.ok) return fail(-2);
     const bool stream_end_known = d->decoded && (d->k_status == CHIP_FINISHED || d->k_status < 0 || d->k_status == CHIP_NEED_DICT);
     size_t taken = 0;
     if (!stream_end_known && in_len) {
-        if (!dec_reserve_in(d, d->h_in_len + in_len)) {
-            r.status = -1;
-            r.err = -4;  // Z_MEM_ERROR
-            return r;
-        }
+        if (!dec_compact(d)) return fail(-4);
+        if (d->h_in_len + in_len > DEC_IN_LIMIT) return fail(-4);  // Z_MEM_ERROR: more buffered input than a unit can address
+        if (!dec_reserve_in(d, d->h_in_len + in_len)) return fail(-4);
         memcpy(d->h_in + d->h_in_len, in, in_len);
         d->h_in_len += in_len;
         taken = in_len;
         d->decoded = false;
     }
-    if (!d->decoded && !dec_run(d)) {
-        r.status = -1;
-        r.err = -4;
-        return r;
-    }
-    size_t avail = d->k_out_len - d->delivered;
-    size_t n = avail < out_len ? avail : out_len;
-    if (n) {
-        (void)hipSetDevice(d->device);
-        if (hipMemcpyAsync(out, d->d_out + d->delivered, n, hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
-            hipStreamSynchronize(d->stream) != hipSuccess) {
-            r.status = -1;
-            r.err = -4;
-            return r;
+    size_t n_total = 0;
+    for (;;) {
+        if (!d->decoded && !dec_run(d)) return fail(-4);
+        const size_t avail = d->k_out_len - d->delivered;
+        const size_t n = avail < out_len - n_total ? avail : out_len - n_total;
+        if (n) {
+            if (hipMemcpyAsync(out + n_total, d->d_out + d->delivered, n, hipMemcpyDeviceToHost, d->stream) != hipSuccess ||
+                hipStreamSynchronize(d->stream) != hipSuccess)
+                return fail(-4);
+            d->delivered += n;
+            n_total += n;
         }
-        d->delivered += n;
+        // everything decoded so far is handed on but the device buffer was the limit: make room and decode on
+        if (d->delivered == d->k_out_len && d->k_status == CHIP_NEED_OUTPUT && d->format != CHIP_FMT_ZSTD && n_total < out_len) {
+            const uint32_t before = d->resume[1];
+            if (!dec_compact(d)) return fail(-4);
+            if (d->resume[1] == before && d->d_out_cap >= DEC_OUT_LIMIT) break;  // nothing could be dropped and nothing can grow
+            d->decoded = false;
+            continue;
+        }
+        break;
     }
+    const size_t n = n_total;
     r.output_remain = out_len - n;
     // bytes of this call that lie behind the end of the stream go back to the caller
     size_t giveback = 0;
@@ -899,7 +980,7 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
         d->h_in_len -= giveback;
     }
     r.input_remain = (in_len - taken) + giveback;
-    if (d->delivered < d->k_out_len) {
+    if (d->delivered < d->k_out_len || d->k_status == CHIP_NEED_OUTPUT) {
         r.status = CHIP_NEED_OUTPUT;
         return r;
     }
@@ -917,16 +998,25 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
     return r;
 }
 
+void chip_decoder_footprint(const chip_decoder *d, size_t *pinned_bytes, size_t *device_bytes)
+{
+    if (pinned_bytes) *pinned_bytes = d ? d->h_in_cap + sizeof(Meta) : 0;
+    if (device_bytes) *device_bytes = d ? d->d_in_cap + d->d_out_cap + sizeof(Meta) + (d->d_zres ? (16 + 2312) * 4 + 64 : 0) : 0;
+}
+
 chip_decoder *chip_decoder_reset(chip_decoder *d)
 {
-    if (d) dec_clear(d);
+    if (d) {
+        DeviceGuard guard(d->device);
+        dec_clear(d);
+    }
     return d;
 }
 
 void chip_decoder_free(chip_decoder *d)
 {
     if (!d) return;
-    (void)hipSetDevice(d->device);
+    DeviceGuard guard(d->device);
     if (d->stream) {
         chip::release_inflate_scratch_of(d->stream);  // the stream's token scratch goes with it
         (void)hipStreamDestroy(d->stream);
@@ -937,7 +1027,8 @@ void chip_decoder_free(chip_decoder *d)
     chip_device_free(d->d_out);
     chip_device_free(d->d_meta);
     chip_device_free(d->d_zres);
-    host_free(d);
+    const Hooks hooks = d->hooks;
+    hooks.release(d);
 }
 
 }  // extern "C"
@@ -991,6 +1082,7 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
 // provides room.
 
 struct chip_encoder {
+    Hooks hooks;  // the allocator this object came from
     int mode, level, device;
     hipStream_t stream;
     uint8_t *h_in;  // pinned: input not yet compressed
@@ -1038,7 +1130,6 @@ void enc_clear(chip_encoder *e)
 // compress the buffered input as one segment and append it to h_out
 bool enc_segment(chip_encoder *e, bool final)
 {
-    if (hipSetDevice(e->device) != hipSuccess) return false;
     const size_t n = e->h_in_len;
     const size_t bound = chip_encode_bound(e->mode, n) + 16;
     if (n + 16 > e->d_in_cap) {
@@ -1103,15 +1194,18 @@ chip_encoder *chip_encoder_new(const chip_encoder_opts *opts)
     if (!device_ok()) return nullptr;  // no CPU codec behind this backend
     int device = opts ? opts->device : -1;
     if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
-    if (hipSetDevice(device) != hipSuccess) return nullptr;
-    chip_encoder *e = (chip_encoder *)host_alloc(sizeof(chip_encoder));
+    DeviceGuard guard(device);
+    if (!guard.ok) return nullptr;
+    const Hooks hooks = current_hooks();
+    chip_encoder *e = (chip_encoder *)hooks.alloc(sizeof(chip_encoder));
     if (!e) return nullptr;
     memset(e, 0, sizeof *e);
+    e->hooks = hooks;
     e->mode = mode;
     e->level = level;
     e->device = device;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
-        host_free(e);
+        hooks.release(e);
         return nullptr;
     }
     e->d_meta = (chip_encoder::EMeta *)chip_device_alloc(sizeof(chip_encoder::EMeta));
@@ -1128,14 +1222,25 @@ chip_encode_result chip_encode(chip_encoder *e, const uint8_t *in, size_t in_len
 {
     chip_encode_result r = {in_len, out_len, CHIP_ENC_ERROR};
     if (!e || op < CHIP_OP_PROCESS || op > CHIP_OP_FINISH) return r;
+    DeviceGuard guard(e->device);
+    if (!guard.ok) return r;
+    // Memory stays bounded: buffered input is compressed as a (byte-aligned, non-final) segment once ENC_SEGMENT bytes have
+    // gathered, and no more input is taken while more than ENC_BACKLOG compressed bytes wait for the caller -- as zlib's
+    // deflate() stops consuming when avail_out is 0.
+    constexpr size_t ENC_SEGMENT = (size_t)1 << 20, ENC_BACKLOG = (size_t)4 << 20;
     size_t taken = 0;
-    if (!e->finished && in_len) {
-        if (!enc_reserve(&e->h_in, &e->h_in_cap, e->h_in_len, e->h_in_len + in_len)) return r;
-        memcpy(e->h_in + e->h_in_len, in, in_len);
-        e->h_in_len += in_len;
-        taken = in_len;
+    while (!e->finished && taken < in_len && e->h_out_len - e->delivered <= ENC_BACKLOG) {
+        const size_t room = ENC_SEGMENT - (e->h_in_len < ENC_SEGMENT ? e->h_in_len : ENC_SEGMENT);
+        const size_t k = in_len - taken < room ? in_len - taken : room;
+        if (!enc_reserve(&e->h_in, &e->h_in_cap, e->h_in_len, e->h_in_len + k)) return r;
+        memcpy(e->h_in + e->h_in_len, in + taken, k);
+        e->h_in_len += k;
+        taken += k;
+        if (e->h_in_len >= ENC_SEGMENT && taken < in_len && !enc_segment(e, false)) return r;  // the rest of this call's input follows
     }
-    if (!e->finished && (op == CHIP_OP_FLUSH || op == CHIP_OP_FINISH) && (e->h_in_len || op == CHIP_OP_FINISH || !e->started)) {
+    if (!e->finished && e->h_in_len >= ENC_SEGMENT && op == CHIP_OP_PROCESS && !enc_segment(e, false)) return r;
+    if (!e->finished && taken == in_len && (op == CHIP_OP_FLUSH || op == CHIP_OP_FINISH) &&
+        (e->h_in_len || op == CHIP_OP_FINISH || !e->started)) {
         if (!enc_segment(e, op == CHIP_OP_FINISH)) return r;
     }
     size_t avail = e->h_out_len - e->delivered, k = avail < out_len ? avail : out_len;
@@ -1160,7 +1265,7 @@ chip_encoder *chip_encoder_reset(chip_encoder *e)
 void chip_encoder_free(chip_encoder *e)
 {
     if (!e) return;
-    (void)hipSetDevice(e->device);
+    DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     chip_pinned_free(e->h_in);
     chip_pinned_free(e->h_out);
@@ -1168,7 +1273,8 @@ void chip_encoder_free(chip_encoder *e)
     chip_device_free(e->d_in);
     chip_device_free(e->d_out);
     chip_device_free(e->d_meta);
-    host_free(e);
+    const Hooks hooks = e->hooks;
+    hooks.release(e);
 }
 
 }  // extern "C"

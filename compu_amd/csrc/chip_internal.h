@@ -24,6 +24,8 @@ constexpr int32_t ZSTD_E_CORRUPTION = 20;
 constexpr int32_t ZSTD_E_CHECKSUM_WRONG = 22;
 constexpr int32_t ZSTD_E_DICT_WRONG = 32;
 
+constexpr uint32_t RESUME_WORDS = 6;
+
 struct BatchArgs {
     const uint8_t *in_base;
     const uint64_t *in_off;
@@ -37,9 +39,16 @@ struct BatchArgs {
     uint32_t n;
     int32_t format;
     unsigned long long *stats;  // diagnostic builds only (-DCHIP_STATS): 16 words per unit, else nullptr
-    // inflate, streaming decoder only (else nullptr): three words per unit, in and out -- bit offset of the last
-    // block boundary reached (0 = start from the beginning), output bytes produced up to there, wrapper kind.
-    // A later call over the same (longer) input and the same output buffer continues from that boundary.
+    // inflate, streaming decoder only (else nullptr): RESUME_WORDS words per unit, in and out --
+    //  [0] bit offset (in the unit's input as it is handed over) of the last block boundary reached, 0 = start from the beginning
+    //  [1] output bytes produced up to there, as an offset into the unit's output range
+    //  [2] wrapper kind (0 raw, 1 zlib, 2 gzip)
+    //  [3] running check value (Adler-32 / CRC-32) over the first [4] bytes of the stream's output
+    //  [4] output bytes the running check covers, counted from the start of the stream
+    //  [5] output bytes the caller has dropped in front of the output range (offset 0 = stream byte [5]), low 32 bits of
+    //      the stream's output count = [5] + offset
+    // A later call over the unconsumed input (the caller may drop input in front of the boundary and output in front of the
+    // 32 KiB window, adjusting [0], [1] and [5]) continues from that boundary.
     uint32_t *resume;
     // Routed batches (CHIP_FMT_DETECT): the kernel works on units sel[0 .. *sel_n) instead of 0 .. n (both device
     // pointers, written by route_kernel earlier on the same stream); nullptr = all n units in index order.

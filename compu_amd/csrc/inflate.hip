@@ -1027,8 +1027,10 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     int32_t format = a.format;
     uint32_t ck_bit = 0, ck_opos = 0;  // last block boundary reached (streaming decoder: where the next call resumes)
     bool resumed = false;
+    uint32_t run_check = 0, run_cov = 0, out_dropped = 0;  // running trailer check: value, stream bytes covered; bytes dropped in front
     if (a.resume) {
-        const uint32_t r0 = a.resume[3u * u], r1 = a.resume[3u * u + 1], r2 = a.resume[3u * u + 2];
+        const uint32_t *rs = a.resume + RESUME_WORDS * u;
+        const uint32_t r0 = rs[0], r1 = rs[1], r2 = rs[2];
         if (r0 != 0 && r0 <= in_len * 8u && r1 <= cap) {
             resumed = true;
             pos = start_bit + r0;
@@ -1036,6 +1038,9 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             wrap = r2 & 3u;
             ck_bit = r0;
             ck_opos = r1;
+            run_check = rs[3];
+            run_cov = rs[4];
+            out_dropped = rs[5];
         }
     }
     if (!resumed && format != CHIP_FMT_DEFLATE) {
@@ -1224,17 +1229,19 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             status = CHIP_NEED_INPUT;
         } else if (wrap == 1) {
             uint32_t want = ((uint32_t)gin[k] << 24) | ((uint32_t)gin[k + 1] << 16) | ((uint32_t)gin[k + 2] << 8) | gin[k + 3];
-            if (rdfirst(wave_adler32(gout, opos)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
+            const uint32_t c0 = run_cov - out_dropped;  // offset the running value (seed) covers up to; 0 and seed 1 for a whole stream
+            if (rdfirst(wave_adler32(gout + c0, opos - c0, resumed ? run_check : 1u)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
             k += 4;
         } else if (in_len - k < 4) {
             status = CHIP_NEED_INPUT;
         } else {
             uint32_t want = gin[k] | ((uint32_t)gin[k + 1] << 8) | ((uint32_t)gin[k + 2] << 16) | ((uint32_t)gin[k + 3] << 24);
-            if (rdfirst(wave_crc32(L.lit_lut, gout, opos)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
+            const uint32_t c0 = run_cov - out_dropped;
+            if (rdfirst(wave_crc32(L.lit_lut, gout + c0, opos - c0, resumed ? run_check : 0u)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
             else if (in_len - k < 8) status = CHIP_NEED_INPUT;
             else {
                 uint32_t isize = gin[k + 4] | ((uint32_t)gin[k + 5] << 8) | ((uint32_t)gin[k + 6] << 16) | ((uint32_t)gin[k + 7] << 24);
-                if (rdfirst(isize) != opos) status = Z_DATA_ERROR;  // incorrect length check
+                if (rdfirst(isize) != out_dropped + opos) status = Z_DATA_ERROR;  // incorrect length check
             }
             k += 8;
         }
@@ -1245,11 +1252,25 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     if (a.stats && lane == 0)
         for (int k = 0; k < 24; k++) a.stats[(size_t)u * 24 + k] = st_[k];
 #endif
-    if (a.resume && lane == 0) {
+    if (a.resume) {
+        // the stream goes on in a later call: bring the running check up to the boundary it will resume from (the bytes in
+        // front of it are final; the caller may drop them once it has handed them on)
         const bool cont = status == CHIP_NEED_INPUT || status == CHIP_NEED_OUTPUT;
-        a.resume[3u * u] = cont ? ck_bit : 0u;
-        a.resume[3u * u + 1] = cont ? ck_opos : 0u;
-        a.resume[3u * u + 2] = wrap;
+        uint32_t *rs = a.resume + RESUME_WORDS * u;
+        if (!resumed) run_check = wrap == 1 ? 1u : 0u;
+        const uint32_t c0 = run_cov - out_dropped;
+        if (cont && wrap && ck_bit != 0 && ck_opos > c0) {
+            run_check = wrap == 1 ? wave_adler32(gout + c0, ck_opos - c0, run_check) : wave_crc32(L.lit_lut, gout + c0, ck_opos - c0, run_check);
+            run_cov = out_dropped + ck_opos;
+        }
+        if (lane == 0) {
+            rs[0] = cont ? ck_bit : 0u;
+            rs[1] = cont ? ck_opos : 0u;
+            rs[2] = wrap;
+            rs[3] = run_check;
+            rs[4] = run_cov;
+            rs[5] = out_dropped;
+        }
     }
     if (lane == 0) {
         uint32_t used = (pos - start_bit + 7u) >> 3;

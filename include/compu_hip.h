@@ -113,13 +113,22 @@ typedef struct {
  * src/decoder/zstd.rs:81-94.  NULL on failure (the Rust side maps NULL to None). */
 chip_decoder *chip_decoder_new(int format, const chip_decoder_opts *opts);
 /* decode_fn: src/decoder/zlib_ng.rs:94-96 (+ macro src/decoder/mod.rs:459-486),
- * src/decoder/zstd.rs:98-136.  `in`/`out` are host pointers borrowed for the call only. */
+ * src/decoder/zstd.rs:98-136.  `in`/`out` are host pointers borrowed for the call only.
+ * Limits: at most 256 MiB of compressed input may be BUFFERED (input behind the last deflate block boundary, or of
+ * one zstd frame) and 4 GiB - 16 of decoded output held; a call that would cross them fails with err = -4
+ * (Z_MEM_ERROR) instead of looping.  The calling thread's current HIP device is left as it was. */
 chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len);
 /* reset_fn: src/decoder/zlib_ng.rs:99-108, src/decoder/zstd.rs:139-148.  Returns the instance
  * to keep using (compu replaces its pointer with the returned one, src/decoder/mod.rs:433-441). */
 chip_decoder *chip_decoder_reset(chip_decoder *d);
 /* drop_fn: src/decoder/zlib_ng.rs:111-115, src/decoder/zstd.rs:151-156 */
 void chip_decoder_free(chip_decoder *d);
+/* Memory a streaming decoder holds right now: pinned host bytes (buffered input) and device bytes (input copy, decoded
+ * output not yet handed on + the 32 KiB window, checkpoint).  An inflate stream keeps O(window + piece) whatever its
+ * length: input in front of the last block boundary and output that has been handed on are dropped between calls (the
+ * reference's state is ~40 KiB per decoder, src/decoder/zlib_ng.rs:29-55).  The kernel's token scratch (48 KiB per
+ * streaming decoder) is not included. */
+void chip_decoder_footprint(const chip_decoder *d, size_t *pinned_bytes, size_t *device_bytes);
 /* describe_error_fn: src/decoder/zlib_ng.rs:118-123 (zError), src/decoder/zstd.rs:159-164
  * (ZSTD_getErrorName).  Never NULL for code 0 (tests/decoder.rs:74-76). */
 const char *chip_decoder_strerror(int format, int32_t code);

@@ -267,3 +267,142 @@ def test_streaming_a_long_gzip_in_small_pieces_is_linear(gpu, alice):
             status = r.status
             break
     assert status == compu.DecodeError(-3)
+
+
+def test_streaming_memory_stays_bounded_over_a_long_gzip(gpu, alice):
+    """A 192 MiB gzip fed in 64 KiB pieces (compu's decode loop, src/decoder/mod.rs:323-335): the decoder drops input in
+    front of the last block boundary and output it has handed on (keeping the 32 KiB window), and carries the trailer
+    CRC as a running value -- its buffers stay O(window + piece) instead of O(stream).  zlib-ng's state is ~40 KiB
+    (src/decoder/zlib_ng.rs:29-55)."""
+    import compu_amd
+
+    rnd = random.Random(77)
+    total = 192 << 20
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    comp = bytearray()
+    crc = 0
+    made = 0
+    while made < total:
+        # text (matches far and near), noise (stored blocks) and runs (long self-overlapping matches), 1 MiB at a time
+        kind = rnd.randrange(3)
+        if kind == 0:
+            s0 = rnd.randrange(0, len(alice) - 65536)
+            blk = (alice[s0 : s0 + 65536]) * 16
+        elif kind == 1:
+            blk = rnd.randbytes(1 << 20)
+        else:
+            blk = bytes([rnd.randrange(256)]) * (1 << 20)
+        crc = zlib.crc32(blk, crc)
+        comp += co.compress(blk)
+        made += len(blk)
+    comp += co.flush()
+    comp = bytes(comp)
+    dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+    out = bytearray(256 << 10)
+    got_crc, got_len, pos, peak_pin, peak_dev = 0, 0, 0, 0, 0
+    free0 = gpu.cuda.mem_get_info()[0]
+    min_free = free0
+    status = None
+    piece = 64 << 10
+    calls = 0
+    while status != compu_amd.DecodeStatus.Finished:
+        chunk = comp[pos : pos + piece]
+        r = dec.decode(chunk, out)
+        assert r.is_ok(), (pos, r.status)
+        n = len(out) - r.output_remain
+        got_crc = zlib.crc32(memoryview(out)[:n], got_crc)
+        got_len += n
+        pos += len(chunk) - r.input_remain
+        status = r.status
+        calls += 1
+        if calls % 64 == 0:
+            pin, devb = dec.footprint()
+            peak_pin, peak_dev = max(peak_pin, pin), max(peak_dev, devb)
+            min_free = min(min_free, gpu.cuda.mem_get_info()[0])
+        assert calls < 200000
+    assert got_len == made and got_crc == crc and pos == len(comp)
+    # one deflate block of level-1 output is at most a few hundred KiB compressed / ~1 MiB decoded: window + piece + block
+    assert peak_pin <= 4 << 20 and peak_dev <= 24 << 20, (peak_pin, peak_dev)
+    assert free0 - min_free <= 64 << 20, (free0, min_free)  # hipMemGetInfo: no growth with the stream's length
+
+
+def test_streaming_input_limit_is_an_error_not_a_hang(gpu):
+    """More than 256 MiB of input buffered behind one block boundary cannot be addressed by the kernels' 32-bit bit
+    offsets: chip_decode answers Err(-4) (Z_MEM_ERROR) instead of wrapping around and asking for input for ever."""
+    import compu_amd
+
+    dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+    hdr = bytes([0x1F, 0x8B, 8, 8, 0, 0, 0, 0, 0, 3])  # FNAME set: the header ends at a zero byte that never comes
+    out = bytearray(1024)
+    r = dec.decode(hdr + b"a" * 4096, out)
+    assert r.status == compu_amd.DecodeStatus.NeedInput
+    big = np.full((256 << 20) + 1, 0x61, np.uint8)
+    r = dec.decode(big, out)
+    assert not r.is_ok() and r.status.as_raw() == -4
+    assert dec.reset()
+    import zlib as _z
+    co = _z.compressobj(6, _z.DEFLATED, 31)
+    small = co.compress(b"hello") + co.flush()
+    r = dec.decode(small, out)
+    assert r.status == compu_amd.DecodeStatus.Finished and bytes(out[:5]) == b"hello"
+
+
+def test_allocator_hooks_are_balanced_and_per_object(gpu):
+    """chip_set_allocator (src/mem.rs:52-57,74-76 routing): host state of decoders and encoders comes from the hooks that
+    were installed when the object was made and goes back to the SAME hooks, whatever is installed later."""
+    import ctypes as C
+
+    import compu_amd
+
+    L = compu_amd.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    libc.free.argtypes = [C.c_void_p]
+    MALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+    FREE = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p)
+
+    def make():
+        live, stats = set(), {"malloc": 0, "free": 0, "foreign": 0}
+
+        def m(opaque, n):
+            p = libc.malloc(n)
+            live.add(p)
+            stats["malloc"] += 1
+            return p
+
+        def f(opaque, p):
+            if p in live:
+                live.remove(p)
+            else:
+                stats["foreign"] += 1
+            stats["free"] += 1
+            libc.free(p)
+
+        return MALLOC(m), FREE(f), live, stats
+
+    mA, fA, liveA, stA = make()
+    mB, fB, liveB, stB = make()
+    try:
+        L.chip_set_allocator(mA, fA, None)
+        dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+        enc = compu_amd.encoder_interface.zlib_hip(compu_amd.ZlibOptions().mode(compu_amd.ZlibMode.Gzip).compression(1))
+        assert stA["malloc"] == 2 and len(liveA) == 2
+        L.chip_set_allocator(mB, fB, None)  # later objects use B; the ones above still belong to A
+        dec2 = compu_amd.decoder_interface.zstd_hip(compu_amd.ZstdOptions())
+        assert stB["malloc"] == 1
+        assert dec.reset() and enc.reset() and dec2.reset()
+        out = bytearray(64)
+        r = enc.encode(b"abc", out, compu_amd.EncodeOp.Finish)
+        n = len(out) - r.output_remain
+        back = bytearray(16)
+        r2 = dec.decode(bytes(out[:n]), back)
+        assert r2.status == compu_amd.DecodeStatus.Finished and bytes(back[:3]) == b"abc"
+        del dec, enc, dec2
+        import gc
+
+        gc.collect()
+        assert stA == {"malloc": 2, "free": 2, "foreign": 0} and not liveA
+        assert stB == {"malloc": 1, "free": 1, "foreign": 0} and not liveB
+    finally:
+        L.chip_set_allocator(None, None, None)
