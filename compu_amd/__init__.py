@@ -9,6 +9,8 @@ construction fails loudly.
 """
 from .api import (  # noqa: F401
     Buffer,
+    DeviceBuffer,
+    PinnedBuffer,
     Decode,
     DecodeError,
     DecodeStatus,

@@ -554,6 +554,118 @@ class Buffer:
         return len(input) - result.input_remain, result.status
 
 
+class PinnedBuffer(Buffer):
+    """Buffer<N>'s cursor API (src/buffer.rs:1-49) over page-locked host memory (chip_pinned_alloc = hipHostMalloc): the
+    north star's pinned-host buffer type.  Used like Buffer with the streaming Decoder / Encoder."""
+
+    def __init__(self, n):
+        import numpy as np
+
+        self._ptr = lib().chip_pinned_alloc(n)
+        if not self._ptr:
+            raise MemoryError("chip_pinned_alloc failed")
+        self._buf = np.ctypeslib.as_array((C.c_uint8 * n).from_address(self._ptr))
+        self.cursor = 0
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            self._buf = None
+            lib().chip_pinned_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """The north star's device buffer type: GPU memory (chip_device_alloc = hipMalloc, where src/mem.rs routes device
+    allocations) with Buffer<N>'s cursor.  upload() appends host bytes, decode_batch() appends decoded units behind the
+    cursor without the data touching the host, download() reads back."""
+
+    def __init__(self, n):
+        self._cap = n
+        self._ptr = lib().chip_device_alloc(n + 16)
+        if not self._ptr:
+            raise MemoryError("chip_device_alloc failed")
+        self.cursor = 0
+
+    def ptr(self, offset=0):
+        return self._ptr + offset
+
+    def __len__(self):
+        return self.cursor
+
+    def capacity(self):
+        return self._cap
+
+    def spare_capacity_len(self):
+        return self._cap - self.cursor
+
+    def consume(self):
+        self.cursor = 0
+
+    def upload(self, data):
+        k, ip, n = _in_ptr(data)
+        if n > self._cap - self.cursor:
+            raise ValueError("does not fit")
+        L = lib()
+        if n and (L.chip_memcpy_h2d(self._ptr + self.cursor, ip, n, None) != 0 or L.chip_stream_sync(None) != 0):
+            raise RuntimeError("upload failed")
+        self.cursor += n
+        return n
+
+    def download(self, offset=0, n=None):
+        import numpy as np
+
+        n = self.cursor - offset if n is None else n
+        assert offset + n <= self.cursor
+        out = np.empty(n, np.uint8)
+        L = lib()
+        if n and (L.chip_memcpy_d2h(out.ctypes.data, self._ptr + offset, n, None) != 0 or L.chip_stream_sync(None) != 0):
+            raise RuntimeError("download failed")
+        return out
+
+    def decode_batch(self, fmt, src, in_off, in_len, out_off, out_cap, span):
+        """chip_decode_batch from DeviceBuffer `src` into this buffer's spare capacity (out_off relative to it); the
+        per-unit arrays are host sequences, uploaded here.  Returns (out_len, in_used, status) as numpy arrays."""
+        import numpy as np
+
+        n = len(in_len)
+        if span > self._cap - self.cursor:
+            raise ValueError("does not fit")
+        host = np.zeros(n * 10 + 16, np.uint32)
+        host[: 2 * n].view(np.uint64)[:] = np.asarray(in_off, np.uint64)
+        host[2 * n : 4 * n].view(np.uint64)[:] = np.asarray(out_off, np.uint64)
+        host[4 * n : 5 * n] = np.asarray(in_len, np.uint32)
+        host[5 * n : 6 * n] = np.asarray(out_cap, np.uint32)
+        arr = DeviceBuffer(host.nbytes)
+        arr.upload(host)
+        a = arr.ptr()
+        L = lib()
+        rc = L.chip_decode_batch(int(fmt), n, src.ptr(), a, a + 16 * n, self._ptr + self.cursor, a + 8 * n, a + 20 * n, a + 24 * n, a + 28 * n,
+                                 a + 32 * n, None)
+        if rc != 0 or L.chip_stream_sync(None) != 0:
+            raise RuntimeError(f"chip_decode_batch failed: {rc}")
+        self.cursor += span
+        res = arr.download(24 * n, 12 * n).view(np.uint32)
+        arr.close()
+        return res[:n].copy(), res[n : 2 * n].copy(), res[2 * n :].view(np.int32).copy()
+
+    def close(self):
+        if getattr(self, "_ptr", None):
+            lib().chip_device_free(self._ptr)
+            self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 # ---- batched entry points on torch CUDA tensors -----------------------------------------------
 
 

@@ -6,7 +6,7 @@
 //       <- src/decoder/mod.rs, src/decoder/zlib_common.rs, src/decoder/zstd.rs
 //   compu::encoder::{Interface, Encoder, Encode, EncodeOp, EncodeStatus, ZlibOptions}
 //       <- src/encoder/mod.rs, src/encoder/zlib_common.rs
-//   compu::Buffer<N>                                                  <- src/buffer.rs
+//   compu::Buffer<N>, compu::PinnedBuffer, compu::DeviceBuffer          <- src/buffer.rs (+ the north star's pinned-host / device types)
 // so that tests/cpp/test_reference.cpp reads like tests/decoder.rs / tests/encoder.rs.  The Rust glue a
 // maintainer would add to the crate itself is in INTEGRATION.md.
 #pragma once
@@ -312,6 +312,102 @@ public:
 
 private:
     uint8_t buf_[N];
+    size_t cursor_ = 0;
+};
+
+// The two buffer types the hip backend adds to src/buffer.rs (north star: "src/buffer.rs grows pinned-host + device
+// buffer types"), with Buffer<N>'s cursor API (data / len / consume / spare capacity; src/buffer.rs:9-49).
+//
+// PinnedBuffer: page-locked host memory (hipHostMalloc through chip_pinned_alloc).  Used exactly like Buffer<N> with the
+// streaming Decoder / Encoder; the copies between it and the GPU are real DMA transfers instead of staged ones.
+class PinnedBuffer {
+public:
+    explicit PinnedBuffer(size_t capacity) : buf_((uint8_t *)chip_pinned_alloc(capacity)), cap_(buf_ ? capacity : 0) {}
+    ~PinnedBuffer() { chip_pinned_free(buf_); }
+    PinnedBuffer(const PinnedBuffer &) = delete;
+    PinnedBuffer &operator=(const PinnedBuffer &) = delete;
+    bool valid() const { return buf_ != nullptr; }
+    const uint8_t *data() const { return buf_; }
+    size_t len() const { return cursor_; }
+    size_t capacity() const { return cap_; }
+    void consume() { cursor_ = 0; }
+    uint8_t *spare_capacity_mut() { return buf_ + cursor_; }
+    size_t spare_capacity_len() const { return cap_ - cursor_; }
+    void advance(size_t n) { cursor_ += n; }  // after writing n bytes into the spare capacity
+
+    std::pair<bool, std::pair<size_t, decoder::DecodeStatus>> decode(decoder::Decoder &dec, const uint8_t *input, size_t input_len,
+                                                                      decoder::DecodeError *err = nullptr)
+    {
+        const size_t spare = cap_ - cursor_;
+        decoder::Decode r = dec.decode(input, input_len, buf_ + cursor_, spare);
+        if (!r.ok) {
+            if (err) *err = r.error;
+            return {false, {0, decoder::DecodeStatus::NeedInput}};
+        }
+        cursor_ += spare - r.output_remain;
+        return {true, {input_len - r.input_remain, r.status}};
+    }
+    std::pair<size_t, encoder::EncodeStatus> encode(encoder::Encoder &enc, const uint8_t *input, size_t input_len, encoder::EncodeOp op)
+    {
+        const size_t spare = cap_ - cursor_;
+        encoder::Encode r = enc.encode(input, input_len, buf_ + cursor_, spare, op);
+        cursor_ += spare - r.output_remain;
+        return {input_len - r.input_remain, r.status};
+    }
+
+private:
+    uint8_t *buf_;
+    size_t cap_;
+    size_t cursor_ = 0;
+};
+
+// DeviceBuffer: memory of the current GPU (hipMalloc through chip_device_alloc; src/mem.rs routes device allocations
+// there).  The batched entry points read and write device memory, so a DeviceBuffer is what a batch decodes out of and
+// into without the data ever touching the host: upload() appends host bytes, decode_batch() appends the decoded units
+// behind the cursor, download() reads back.
+class DeviceBuffer {
+public:
+    explicit DeviceBuffer(size_t capacity) : buf_((uint8_t *)chip_device_alloc(capacity + 16)), cap_(buf_ ? capacity : 0) {}
+    ~DeviceBuffer() { chip_device_free(buf_); }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+    bool valid() const { return buf_ != nullptr; }
+    const uint8_t *data() const { return buf_; }  // DEVICE pointer to the written part
+    size_t len() const { return cursor_; }
+    size_t capacity() const { return cap_; }
+    void consume() { cursor_ = 0; }
+    uint8_t *spare_capacity_mut() { return buf_ + cursor_; }  // DEVICE pointer
+    size_t spare_capacity_len() const { return cap_ - cursor_; }
+    void advance(size_t n) { cursor_ += n; }
+
+    // append host bytes (synchronous); false when they do not fit
+    bool upload(const uint8_t *src, size_t n)
+    {
+        if (n > cap_ - cursor_) return false;
+        if (n && (chip_memcpy_h2d(buf_ + cursor_, src, n, nullptr) != CHIP_OK || chip_stream_sync(nullptr) != CHIP_OK)) return false;
+        cursor_ += n;
+        return true;
+    }
+    // copy `n` written bytes from offset `from` to the host (synchronous)
+    bool download(uint8_t *dst, size_t from, size_t n) const
+    {
+        if (from + n > cursor_) return false;
+        return n == 0 || (chip_memcpy_d2h(dst, buf_ + from, n, nullptr) == CHIP_OK && chip_stream_sync(nullptr) == CHIP_OK);
+    }
+    // chip_decode_batch with this buffer's spare capacity as the output: unit i lands at spare + out_off[i] (device
+    // arrays, as in chip_decode_batch); `span` bytes behind the cursor become part of the data.  Only enqueues.
+    int decode_batch(int format, size_t n, const DeviceBuffer &in, const uint64_t *in_off, const uint32_t *in_len, const uint64_t *out_off,
+                     const uint32_t *out_cap, uint32_t *out_len, uint32_t *in_used, int32_t *status, size_t span, void *stream = nullptr)
+    {
+        if (span > cap_ - cursor_) return CHIP_E_INVALID;
+        const int rc = chip_decode_batch(format, n, in.data(), in_off, in_len, buf_ + cursor_, out_off, out_cap, out_len, in_used, status, stream);
+        if (rc == CHIP_OK) cursor_ += span;
+        return rc;
+    }
+
+private:
+    uint8_t *buf_;
+    size_t cap_;
     size_t cursor_ = 0;
 };
 

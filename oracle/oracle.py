@@ -219,5 +219,5 @@ def inflate_units(mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap,
     return _units(lib().orc_inflate_units, mode, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads, out)
 
 
-def zstd_units(in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads=1):
-    return _units(lib().orc_zstd_units, None, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads)
+def zstd_units(in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads=1, out=None):
+    return _units(lib().orc_zstd_units, None, in_buf, in_off, in_len, out_cap_total, out_off, out_cap, threads, out)

@@ -87,6 +87,27 @@ static void decoder_test_case(Decoder &decoder, const std::vector<uint8_t> &data
     CHECK(data == output);
     decoder.reset();
 
+    // Buffered decoder over page-locked memory: the hip backend's PinnedBuffer with Buffer<N>'s cursor API
+    {
+        PinnedBuffer pinned(4096);
+        CHECK(pinned.valid() && pinned.capacity() == 4096 && pinned.len() == 0);
+        buffer_input = compressed.data();
+        buffer_input_len = compressed.size();
+        output.clear();
+        for (;;) {
+            DecodeError err;
+            auto r = pinned.decode(decoder, buffer_input, buffer_input_len, &err);
+            CHECK(r.first);
+            buffer_input += r.second.first;
+            buffer_input_len -= r.second.first;
+            output.insert(output.end(), pinned.data(), pinned.data() + pinned.len());
+            pinned.consume();
+            if (r.second.second == DecodeStatus::Finished) break;
+        }
+        CHECK(data == output);
+        decoder.reset();
+    }
+
     // Full vec
     output.clear();
     output.shrink_to_fit();
@@ -97,6 +118,49 @@ static void decoder_test_case(Decoder &decoder, const std::vector<uint8_t> &data
     decoder.reset();
 
     CHECK(decoder.describe_error(DecodeError::no_error()) != nullptr);
+}
+
+// The hip backend's DeviceBuffer: a batch is decoded from device memory into device memory behind the buffer's cursor.
+static void device_buffer_case(const std::vector<uint8_t> &compressed, const std::vector<uint8_t> &data, int format)
+{
+    const size_t n = 3;  // the same stream three times, as three units
+    const size_t in_stride = (compressed.size() + 3) & ~(size_t)3, out_stride = (data.size() + 15) & ~(size_t)15;
+    DeviceBuffer in(n * in_stride), out(64 + n * out_stride), arrays(n * 40 + 64);
+    CHECK(in.valid() && out.valid() && arrays.valid());
+    std::vector<uint8_t> padded(in_stride, 0);
+    memcpy(padded.data(), compressed.data(), compressed.size());
+    for (size_t i = 0; i < n; i++) CHECK(in.upload(padded.data(), padded.size()));
+    CHECK(in.len() == n * in_stride && in.spare_capacity_len() == 0);
+    // per-unit arrays: in_off u64[n], out_off u64[n], in_len u32[n], out_cap u32[n], then results out_len, in_used, status
+    std::vector<uint8_t> host(n * 40, 0);
+    uint64_t *in_off = (uint64_t *)host.data(), *out_off = in_off + n;
+    uint32_t *in_len = (uint32_t *)(out_off + n), *out_cap = in_len + n;
+    for (size_t i = 0; i < n; i++) {
+        in_off[i] = i * in_stride;
+        out_off[i] = i * out_stride;
+        in_len[i] = (uint32_t)compressed.size();
+        out_cap[i] = (uint32_t)data.size();
+    }
+    CHECK(arrays.upload(host.data(), host.size()));
+    const uint8_t *d = arrays.data();
+    const uint64_t *d_in_off = (const uint64_t *)d, *d_out_off = d_in_off + n;
+    const uint32_t *d_in_len = (const uint32_t *)(d_out_off + n), *d_out_cap = d_in_len + n;
+    uint32_t *d_res = (uint32_t *)(d_out_cap + n);
+    const uint8_t marker[16] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+    CHECK(out.upload(marker, sizeof marker));  // the batch lands BEHIND what the buffer already holds
+    CHECK(out.decode_batch(format, n, in, d_in_off, d_in_len, d_out_off, d_out_cap, d_res, d_res + n, (int32_t *)(d_res + 2 * n), n * out_stride) == CHIP_OK);
+    CHECK(chip_stream_sync(nullptr) == CHIP_OK);
+    CHECK(out.len() == 16 + n * out_stride);
+    std::vector<uint8_t> back(out.len());
+    CHECK(out.download(back.data(), 0, back.size()));
+    CHECK(memcmp(back.data(), marker, 16) == 0);
+    for (size_t i = 0; i < n; i++) CHECK(memcmp(back.data() + 16 + i * out_stride, data.data(), data.size()) == 0);
+    std::vector<uint8_t> res(n * 12);
+    CHECK(chip_memcpy_d2h(res.data(), d_res, res.size(), nullptr) == CHIP_OK && chip_stream_sync(nullptr) == CHIP_OK);
+    const uint32_t *r = (const uint32_t *)res.data();
+    for (size_t i = 0; i < n; i++) CHECK(r[i] == data.size() && r[n + i] == compressed.size() && (int32_t)r[2 * n + i] == CHIP_FINISHED);
+    out.consume();
+    CHECK(out.len() == 0 && out.spare_capacity_len() == out.capacity());
 }
 
 // tests/encoder.rs:10-78
@@ -226,6 +290,13 @@ int main(int argc, char **argv)
         for (int i = 0; i < 2; i++) encoder_test_case(*enc, *dec, DATA[i], m.det);
         for (int i = 0; i < 2; i++) encoder_test_case_empty_final(*enc, *dec, DATA[i]);
         std::printf("should_encode_and_decode_zlib_hip_%s (+ empty_final) ... ok\n", m.name);
+    }
+    {  // the hip backend's device buffer type (north star: src/buffer.rs grows pinned-host + device buffer types)
+        for (int i = 0; i < 2; i++) {
+            device_buffer_case(DATA_GZIP[i], DATA[i], CHIP_FMT_GZIP);
+            device_buffer_case(DATA_ZSTD[i], DATA[i], CHIP_FMT_ZSTD);
+        }
+        std::puts("device_buffer_batch_decode ... ok");
     }
     std::puts("test result: ok");
     return 0;

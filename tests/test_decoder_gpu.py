@@ -406,3 +406,52 @@ def test_allocator_hooks_are_balanced_and_per_object(gpu):
         assert stB == {"malloc": 1, "free": 1, "foreign": 0} and not liveB
     finally:
         L.chip_set_allocator(None, None, None)
+
+
+def test_pinned_and_device_buffer_types(gpu, alice):
+    """The north star's buffer types (src/buffer.rs grows pinned-host + device buffers): PinnedBuffer behaves like Buffer<N>
+    (tests/decoder.rs:46-58 replayed over it); DeviceBuffer takes a batch from device memory to device memory."""
+    import compu_amd
+
+    comp = golden("alice29.txt.compressed.gz")
+    dec = compu_amd.decoder_interface.zlib_hip(compu_amd.ZlibMode.Gzip)
+    buf = compu_amd.PinnedBuffer(4096)
+    rest, out = comp, bytearray()
+    while True:
+        used, status = buf.decode(dec, rest)
+        rest = rest[used:]
+        out += buf.data()
+        buf.consume()
+        if status == compu_amd.DecodeStatus.Finished:
+            break
+    assert bytes(out) == alice
+    enc = compu_amd.encoder_interface.zlib_hip(compu_amd.ZlibOptions().mode(compu_amd.ZlibMode.Gzip).compression(1))
+    rest, packed = alice, bytearray()
+    while True:
+        used, status = buf.encode(enc, rest, compu_amd.EncodeOp.Finish)
+        rest = rest[used:]
+        packed += buf.data()
+        buf.consume()
+        assert status != compu_amd.EncodeStatus.Error
+        if status == compu_amd.EncodeStatus.Finished:
+            break
+    assert zlib.decompress(bytes(packed), 31) == alice
+    buf.close()
+    # device to device: three units behind bytes the buffer already holds
+    n = 3
+    stride_in, stride_out = (len(comp) + 3) & ~3, (len(alice) + 15) & ~15
+    src = compu_amd.DeviceBuffer(n * stride_in)
+    for _ in range(n):
+        src.upload(comp + b"\0" * (stride_in - len(comp)))
+    dst = compu_amd.DeviceBuffer(16 + n * stride_out)
+    dst.upload(bytes(range(16)))
+    ol, iu, st = dst.decode_batch(31, src, [i * stride_in for i in range(n)], [len(comp)] * n, [i * stride_out for i in range(n)], [len(alice)] * n,
+                                  n * stride_out)
+    assert (st == 2).all() and (ol == len(alice)).all() and (iu == len(comp)).all()
+    assert len(dst) == 16 + n * stride_out and dst.spare_capacity_len() == 0
+    back = dst.download()
+    assert bytes(back[:16]) == bytes(range(16))
+    for i in range(n):
+        assert bytes(back[16 + i * stride_out : 16 + i * stride_out + len(alice)]) == alice
+    dst.consume()
+    assert len(dst) == 0

@@ -96,6 +96,54 @@ def test_raw_deflate_small_units(gpu, alice):
         assert outs[i] == ref[i][0] and iu[i] == ref[i][1] and st[i] == ref[i][2], i
 
 
+@pytest.mark.timeout(900)
+def test_full_size_batches_match_the_oracle(gpu):
+    """BASELINE.json's full size -- 65,536 units x 64 KiB -- for the dynamic-Huffman config and the mixed gzip+zstd config:
+    the GPU output equals the payload on the device, the oracle's output of the same units equals the payload on the host
+    (so GPU == oracle, byte for byte, without moving 4 GiB twice), and out_len / in_used / status equal the oracle's."""
+    import compu_amd
+    from bench_support import synth
+    from oracle import oracle as O
+
+    n = 65536
+    threads = min(32, len(os.sched_getaffinity(0)))
+    pay = synth.payloads(n, threads=threads)
+    dev = "cuda:0"
+    d_pay = gpu.from_numpy(pay).to(dev)
+    ooff = np.arange(n, dtype=np.uint64) * synth.UNIT
+    caps = np.full(n, synth.UNIT, np.uint32)
+    for kind in ("dynamic", "mixed"):
+        if kind == "mixed":
+            packed, offs, lens = synth.mixed_units(pay, n, threads=threads)
+        else:
+            packed, offs, lens = synth.deflate_units(pay, n, kind=kind, threads=threads)
+        d_out = gpu.zeros(n * synth.UNIT, dtype=gpu.uint8, device=dev)
+        ol, iu, st = compu_amd.decode_batch(
+            0 if kind == "mixed" else -15, gpu.from_numpy(packed).to(dev), gpu.from_numpy(offs.astype(np.int64)).to(dev),
+            gpu.from_numpy(lens.astype(np.int32)).to(dev), d_out, gpu.from_numpy(ooff.astype(np.int64)).to(dev), gpu.from_numpy(caps.astype(np.int32)).to(dev))
+        gpu.cuda.synchronize()
+        assert gpu.equal(d_out, d_pay), kind
+        del d_out
+        ol, iu, st = ol.cpu().numpy().astype(np.uint32), iu.cpu().numpy().astype(np.uint32), st.cpu().numpy()
+        if kind == "mixed":
+            is_gz = packed[offs.astype(np.int64)] == 0x1F
+            gz, zs = np.flatnonzero(is_gz), np.flatnonzero(~is_gz)
+            assert len(gz) > n // 3 and len(zs) > n // 3
+            ref = np.zeros(n * synth.UNIT, np.uint8)  # both oracles decode into the one buffer, each its own units
+            r_len, r_st = np.zeros(n, np.uint32), np.zeros(n, np.int32)
+            _o, r_len[gz], r_st[gz], bad_g = O.inflate_units(O.MODE_GZIP, packed, offs[gz], lens[gz], n * synth.UNIT, ooff[gz], caps[gz], threads=threads, out=ref)
+            _o, r_len[zs], r_st[zs], bad_z = O.zstd_units(packed, offs[zs], lens[zs], n * synth.UNIT, ooff[zs], caps[zs], threads=threads, out=ref)
+            assert bad_g == 0 and bad_z == 0 and np.array_equal(ref, pay)
+            assert (st == r_st).all() and (ol == r_len).all() and (st == 2).all() and (iu == lens).all()
+            del ref
+        else:
+            ref, r_len, r_st, bad = O.inflate_units(O.MODE_DEFLATE, packed, offs, lens, n * synth.UNIT, ooff, caps, threads=threads)
+            assert bad == 0 and np.array_equal(ref, pay)
+            assert (st == r_st).all() and (ol == r_len).all() and (st == 2).all() and (iu == lens).all()
+            del ref
+        del packed
+
+
 def test_raw_deflate_64k_synthetic_units(gpu):
     from bench_support import synth
 
@@ -135,13 +183,17 @@ def test_truncated_corrupt_and_small_caps_match_oracle(gpu, alice):
     for i in range(len(parts)):
         r_out, r_used, r_st = ref[i]
         assert outs[i] == r_out, (i, len(outs[i]), len(r_out))
-        if st[i] == 1 and r_st == 0 and len(r_out) == caps[i]:
-            # output full and no input byte left: zlib says Z_OK/avail_in==0, which compu reads as
-            # NeedInput (mod.rs:476-479); the batch API reports the real cause
+        # The two places where the batch status is, by its documented contract (include/compu_hip.h, chip_decode_batch), the
+        # cause rather than compu's mapping of zlib's return code -- each pinned to its exact condition, everything else equal:
+        if r_st == 0 and len(r_out) == caps[i] and len(parts[i]) and r_used == len(parts[i]) and ol[i] == caps[i] and st[i] != 0:
+            # output full AND every input byte consumed: zlib says Z_OK with avail_in == 0, which compu reads as NeedInput
+            # (mod.rs:476-479); the batch API names the limit that was hit
+            assert st[i] == 1, (i, st[i])
             continue
-        if len(parts[i]) == 0 and st[i] == 0 and r_st == 1:
-            # empty input: zlib answers Z_BUF_ERROR (no progress), which compu maps to NeedOutput
-            # (mod.rs:481); the batch API calls an empty unit what it is: truncated
+        if len(parts[i]) == 0:
+            # empty input: zlib answers Z_BUF_ERROR (no progress), which compu maps to NeedOutput (mod.rs:481); the batch
+            # API calls an empty unit what it is: truncated
+            assert r_st == 1 and st[i] == 0 and ol[i] == 0, (i, st[i], r_st)
             continue
         assert st[i] == r_st, (i, st[i], r_st)
         if r_st == 2:

@@ -106,10 +106,13 @@ def test_truncated_and_corrupt_frames_match_oracle(gpu, alice):
     for i in range(len(parts)):
         r_out, r_used, r_st = ref[i]
         if r_st == 1:
-            # the corrupted frame regenerates more than the capacity: the oracle hands out bytes up to
-            # the capacity, the batch kernel counts whole blocks only (include/compu_hip.h)
-            assert st[i] in (1, -70, -20), (i, st[i])
-            assert outs[i] == r_out[: len(outs[i])]
+            # The (corrupted) frame regenerates more than the capacity.  The streaming oracle stops the moment the output is
+            # full; the batch kernel works on whole blocks (include/compu_hip.h, chip_decode_batch): it either reports the
+            # same NeedOutput, with the whole blocks that fit, or -- when the block that does not fit is itself broken --
+            # the verdict the oracle reaches on that frame once capacity is no object.  Nothing else.
+            big = oracle_zstd_batch([parts[i]], [caps[i] + (1 << 20)])[0]
+            assert st[i] == 1 or (big[2] < 0 and st[i] == big[2]), (i, st[i], big[2])
+            assert len(outs[i]) <= caps[i] and outs[i] == r_out[: len(outs[i])]
             continue
         assert st[i] == r_st, (i, st[i], r_st)
         if r_st in (0, 2):

@@ -68,8 +68,9 @@ for it in range(n_streams):
             break
         if pos >= len(comp) and r.output_remain == len(obuf) and r.status in (compu.DecodeStatus.NeedInput, compu.DecodeStatus.NeedOutput):
             # nothing left to feed and nothing came out: the stream is truncated (an empty call is zlib's Z_BUF_ERROR,
-            # which compu reads as NeedOutput, src/decoder/mod.rs:481)
-            status = 0
+            # which compu reads as NeedOutput, src/decoder/mod.rs:481).  The oracle sees the whole input in ONE call: it
+            # says NeedInput for a stream cut short -- and NeedOutput for an EMPTY stream, whose only call is that empty call.
+            status = 1 if len(comp) == 0 else 0
             break
     want = ref_err if ref_err else ref_st
     got = status
