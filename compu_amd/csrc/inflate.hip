@@ -90,6 +90,16 @@ constexpr int XT_BITS_FIXED = CHIP_XT_BITS_FIXED;
 constexpr int ROW_TOKENS = CHIP_ROW_TOKENS;
 static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0, "geometry");
 constexpr int ROW_WORDS = S_BITS / 32;  // boundary bitmap words per lane (own segment only)
+// x / S_BITS for x < 2^15 (bit offsets inside a super-round) as a multiply and a shift
+constexpr uint32_t SEG_SHIFT = 22;
+constexpr uint32_t SEG_MAGIC = ((1u << SEG_SHIFT) + S_BITS - 1) / S_BITS;
+constexpr bool seg_magic_ok()
+{
+    for (uint32_t x = 0; x < 64u * S_BITS + 4096u; x++)
+        if (((x * SEG_MAGIC) >> SEG_SHIFT) != x / S_BITS) return false;
+    return true;
+}
+static_assert(seg_magic_ok() && (64u * S_BITS + 4096u) * (uint64_t)SEG_MAGIC < (1ull << 32), "segment index by multiplication");
 constexpr int IN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
 static_assert(IN_DW >= 320, "table-build scratch lives in the input window");
 constexpr size_t SCRATCH_WORDS_PER_WAVE = (size_t)64 * ROW_TOKENS;
@@ -153,43 +163,6 @@ __device__ __forceinline__ uint32_t canon_lookup(const HuffMeta &H, const uint32
 #pragma unroll
     for (int j = 1; j < 15; j++) l += (x15 >= H.limit15[j]) ? 1u : 0u;
     return sorted[H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l))];
-}
-
-// Codes longer than the root table are resolved canonically from wave-uniform registers (no LDS
-// traffic besides the final sorted[] read).  q[j] describes length l = ROOT+1+j:
-//   [15:0] limit15[l-1] (start of the length-l code space), [24:16] offs[l], [28:25] 15-l
-template <int ROOT>
-struct LongCodes {
-    uint32_t q[15 - ROOT];
-    uint32_t top;  // limit15[15]: code space at and above it is unused (incomplete set)
-    uint32_t bad;  // entry returned for unused code space
-};
-
-template <int ROOT>
-__device__ __forceinline__ LongCodes<ROOT> load_long_codes(const HuffMeta &H)
-{
-    LongCodes<ROOT> lc;
-#pragma unroll
-    for (int j = 0; j < 15 - ROOT; j++) {
-        const int l = ROOT + 1 + j;
-        lc.q[j] = rdfirst(H.limit15[l - 1] | (H.offs[l] << 16) | ((uint32_t)(15 - l) << 25));
-    }
-    lc.top = rdfirst(H.limit15[15]);
-    uint32_t ml = rdfirst(H.maxlen);
-    lc.bad = mk_entry(ml ? ml : 1u, 0, K_BAD, 0);
-    return lc;
-}
-
-template <int ROOT>
-__device__ __forceinline__ uint32_t long_lookup(const LongCodes<ROOT> &lc, const uint32_t *sorted, uint32_t x15)
-{
-    uint32_t q = lc.q[0];
-#pragma unroll
-    for (int j = 1; j < 15 - ROOT; j++)
-        if (x15 >= (lc.q[j] & 0xffffu)) q = lc.q[j];
-    uint32_t k = ((q >> 16) & 0x1ffu) + ((x15 - (q & 0xffffu)) >> (q >> 25));
-    uint32_t e = sorted[k < 288u ? k : 0u];
-    return x15 >= lc.top ? lc.bad : e;
 }
 
 // Build a canonical Huffman decode table from code lengths (RFC 1951 sec. 3.2.2) with zlib's
@@ -807,13 +780,14 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
 
 // ---- per-lane token decode (lanes are at different bit positions) ---------------------------------
 
-// resolve a root entry that marks a code longer than the root table
+// resolve a root entry that marks a code longer than the root table: through the sub-tables, or -- when a block's long
+// codes need more sub-table entries than there is room for (possible in theory, not seen) -- canonically from the
+// sorted symbols that then still sit where the sub-tables would (slow: the table description is read from LDS)
 template <int ROOT>
-__device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, uint32_t e, uint32_t bits, const LongCodes<ROOT> &lc,
-                                               const uint32_t *sorted)
+__device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, uint32_t e, uint32_t bits, const HuffMeta &H, const uint32_t *sorted)
 {
     if (use_sub) return L.lit_sorted[(e >> 16) + bfe(bits, ROOT, (e >> 4) & 15u)];
-    return long_lookup<ROOT>(lc, sorted, __brev(bits) >> 17);
+    return canon_lookup(H, sorted, __brev(bits) >> 17);
 }
 
 // why a lane stopped walking
@@ -828,8 +802,6 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
     const uint32_t lane = lane_id();
     pos = rdfirst(pos);
     opos = rdfirst(opos);
-    const LongCodes<LIT_ROOT> lcl = load_long_codes<LIT_ROOT>(L.lit_h);
-    const LongCodes<DIST_ROOT> lcd = load_long_codes<DIST_ROOT>(L.dist_h);
     const bool use_sub = rdfirst(L.use_sub) != 0;
     uint32_t *const myrow = grow + lane * ROW_TOKENS;
     for (;;) {
@@ -850,7 +822,6 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         uint32_t lim = s + S_BITS + xt_bits;
         if (lim > B + 64u * S_BITS) lim = B + 64u * S_BITS;  // nobody to join behind the last segment
         uint32_t p = s, nst = 0, reason = R_LIMIT, jl = 64, aux = s;
-        uint32_t segc = lane, off = 0;  // p = B + segc * S_BITS + off
         bool active = s < end_bit;
         while (__any(active)) {
             STAT_ADD(11, 1);
@@ -860,8 +831,10 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 // the boundary at p: marked in the lane's own row, looked up in the row of the segment's owner elsewhere
-                // (segment and offset inside it are carried along: no division; a stopped lane keeps a harmless index)
-                const uint32_t seg = segc & 63u;
+                // (segment and offset inside it by a multiplication; a stopped lane keeps a harmless index)
+                const uint32_t rel = p - B;
+                const uint32_t seg = ((rel * SEG_MAGIC) >> SEG_SHIFT) & 63u;
+                const uint32_t off = rel - seg * (uint32_t)S_BITS;
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&L.rows[(off >> 5) * 64 + seg], (active && seg == lane) ? bit : 0u);
                 const bool joined = active && seg != lane && (old & bit);
@@ -870,13 +843,13 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                 uint32_t lo, hi;
                 win_bits(L, w, p, lo, hi);
                 uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-                if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, lcl, L.lit_sorted);
+                if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, L.lit_h, L.lit_sorted);
                 const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
                 const uint32_t n1 = cl + eb;
                 const bool islen = kind == K_LEN;
                 const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
                 uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-                if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, lcd, L.dist_sorted);
+                if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, L.dist_h, L.dist_sorted);
                 const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
                 const uint32_t tb = n1 + (islen ? cl2 + eb2 : 0u);
                 t4[j] = islen ? tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2)) : tok_lit(e >> 16);
@@ -894,10 +867,6 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                 }
                 nst += go ? 1u : 0u;
                 p += go ? tb : 0u;
-                off += go ? tb : 0u;
-                const bool wrap = off >= (uint32_t)S_BITS;
-                off -= wrap ? (uint32_t)S_BITS : 0u;
-                segc += wrap ? 1u : 0u;
                 active = go && p < lim && nst < (uint32_t)ROW_TOKENS;
                 if (go && !active) aux = p;  // reason stays R_LIMIT: the chain simply ends here
             }
