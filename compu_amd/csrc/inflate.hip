@@ -401,10 +401,17 @@ __device__ int32_t parse_wrapper(uint32_t *tab, const uint8_t *gin, uint32_t ava
     return ST_RUNNING;
 }
 
-// Stored-block payload: copy n bytes from byte offset `so` of the unit's dword-aligned input view
-// to gdst.  Byte copies bring the destination to 16-byte alignment, then every lane moves 16 bytes
-// per trip: dwordx4 + dword loads from the (at most 4-byte aligned) source, a funnel shift by the
-// source's byte misalignment, one aligned dwordx4 store -- a structured memcpy at HBM rate.
+// unaligned accesses (gfx950 handles any byte alignment for LDS and global dword accesses); LDS pointers carry their
+// address space so that a choice between an LDS and a global source never turns into a flat access
+struct __attribute__((packed)) U32u { uint32_t v; };
+struct __attribute__((packed)) U16u { uint16_t v; };
+struct __attribute__((packed)) U128u { uint32_t x, y, z, w; };
+#define LDS_AS __attribute__((address_space(3)))
+typedef LDS_AS uint8_t lds_u8;
+
+// Stored-block payload: copy n bytes from byte offset `so` of the unit's input to gdst.  Byte copies bring the
+// destination to 16-byte alignment, then every lane moves 16 bytes per trip, two trips in flight: one (unaligned) dwordx4
+// load straight from the source -- gfx950 takes any byte alignment -- and one aligned dwordx4 store: a memcpy at HBM rate.
 __device__ void wave_copy_stored(uint8_t *gdst, const uint32_t *g32, uint32_t total_dw, uint32_t so, uint32_t n)
 {
     const uint32_t lane = lane_id();
@@ -413,26 +420,26 @@ __device__ void wave_copy_stored(uint8_t *gdst, const uint32_t *g32, uint32_t to
     if (head > n) head = n;
     if (lane < head) gdst[lane] = gsrc[lane];
     uint32_t done = head;
-    const uint32_t body = (n - done) & ~15u;
+    const uint32_t body = (n - done) & ~15u;  // every 16-byte read lies inside the n source bytes
     if (body) {
-        const uint32_t sb = so + done;          // source byte offset of the body
-        const uint32_t sd = sb >> 2, sh = (sb & 3u) * 8u;
         uint4 *d16 = (uint4 *)(gdst + done);
-        for (uint32_t i = lane; i < (body >> 4); i += 64) {
-            const uint32_t w0 = sd + 4u * i;
-            uint32_t a0 = g32[w0], a1 = g32[w0 + 1], a2 = g32[w0 + 2], a3 = g32[w0 + 3];
-            uint32_t a4 = (sh && w0 + 4 < total_dw) ? g32[w0 + 4] : 0u;
-            uint4 o;
-            o.x = __builtin_amdgcn_alignbit(a1, a0, sh);
-            o.y = __builtin_amdgcn_alignbit(a2, a1, sh);
-            o.z = __builtin_amdgcn_alignbit(a3, a2, sh);
-            o.w = __builtin_amdgcn_alignbit(a4, a3, sh);
-            d16[i] = o;
+        const U128u *s16 = (const U128u *)(gsrc + done);
+        const uint32_t cnt = body >> 4;
+        uint32_t i = lane;
+        for (; i + 64u < cnt; i += 128u) {
+            const U128u a = s16[i], c = s16[i + 64u];
+            d16[i] = make_uint4(a.x, a.y, a.z, a.w);
+            d16[i + 64u] = make_uint4(c.x, c.y, c.z, c.w);
+        }
+        if (i < cnt) {
+            const U128u a = s16[i];
+            d16[i] = make_uint4(a.x, a.y, a.z, a.w);
         }
         done += body;
     }
     const uint32_t tail = n - done;
     if (lane < tail) gdst[done + lane] = gsrc[done + lane];
+    (void)total_dw;
 }
 
 // (off % d) for off, d < 512 without an integer divide
@@ -484,14 +491,6 @@ __device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
     c.tok = c.out + IMG_WORDS + 2 * MQ_CAP;
     return c;
 }
-
-// unaligned accesses (gfx950 handles any byte alignment for LDS and global dword accesses); LDS pointers carry their
-// address space so that a choice between an LDS and a global source never turns into a flat access
-struct __attribute__((packed)) U32u { uint32_t v; };
-struct __attribute__((packed)) U16u { uint16_t v; };
-struct __attribute__((packed)) U128u { uint32_t x, y, z, w; };
-#define LDS_AS __attribute__((address_space(3)))
-typedef LDS_AS uint8_t lds_u8;
 
 // exactly n (1..16) bytes of v to the LDS address d
 __device__ __forceinline__ void lds_put(lds_u8 *d, const U128u &v, uint32_t n)
