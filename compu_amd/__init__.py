@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     Vec,
     ZlibMode,
     ZlibOptions,
+    ZlibStrategy,
     ZstdOptions,
     decode_batch,
     decode_batch_host,

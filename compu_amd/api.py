@@ -31,7 +31,7 @@ class _DecoderOpts(C.Structure):
 
 
 class _EncoderOpts(C.Structure):
-    _fields_ = [("mode", C.c_int32), ("compression", C.c_int32), ("device", C.c_int32)]
+    _fields_ = [("mode", C.c_int32), ("compression", C.c_int32), ("device", C.c_int32), ("strategy", C.c_int32), ("mem_level", C.c_int32)]
 
 
 _lib = None
@@ -104,6 +104,8 @@ def lib():
     L.chip_encoder_free.argtypes = [vp]
     L.chip_encode_batch.restype = C.c_int
     L.chip_encode_batch.argtypes = [C.c_int, C.c_int, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.chip_encode_batch_ex.restype = C.c_int
+    L.chip_encode_batch_ex.argtypes = [C.c_int, C.c_int, C.c_int, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.chip_encode_bound.restype = sz
     L.chip_encode_bound.argtypes = [C.c_int, sz]
     _lib = L
@@ -217,12 +219,35 @@ class Encode:
         return f"Encode(input_remain={self.input_remain}, output_remain={self.output_remain}, status={self.status!r})"
 
 
+class ZlibStrategy(enum.IntEnum):
+    """src/encoder/zlib_common.rs:5-24"""
+
+    Default = 0
+    Filtered = 1
+    HuffmanOnly = 2
+    Rle = 3
+    Fixed = 4
+
+
 class ZlibOptions:
-    """src/encoder/zlib_common.rs:47-103 (defaults: Gzip, level 9, zlib_common.rs:59-66)"""
+    """src/encoder/zlib_common.rs:47-103 (defaults: Gzip, Default strategy, mem_level 8, level 9: zlib_common.rs:59-66)"""
 
     def __init__(self):
         self._mode = ZlibMode.Gzip
         self._compression = 9
+        self._strategy = ZlibStrategy.Default
+        self._mem_level = 8
+
+    def strategy(self, strategy):
+        self._strategy = ZlibStrategy(strategy)
+        return self
+
+    def mem_level(self, mem_level):
+        # the reference's setter asserts `mem_level > MAX_MEM_LEVEL` (an inverted check, zlib_common.rs:88); the value that
+        # reaches deflateInit2_ must be 1..9, which is what the backend accepts
+        assert 0 < mem_level <= 9
+        self._mem_level = mem_level
+        return self
 
     def mode(self, mode):
         assert mode in (ZlibMode.Deflate, ZlibMode.Zlib, ZlibMode.Gzip)
@@ -230,7 +255,7 @@ class ZlibOptions:
         return self
 
     def compression(self, level):
-        assert 0 <= level <= 9
+        assert -1 <= level <= 9  # -1 = zlib's default (zlib_common.rs:96-103)
         self._compression = level
         return self
 
@@ -514,7 +539,7 @@ class encoder_interface:
     def zlib_hip(opts=None, device=-1):
         """Interface::zlib_ng(opts), src/encoder/zlib_ng.rs:50-87; None on failure."""
         opts = opts or ZlibOptions()
-        o = _EncoderOpts(int(opts._mode), opts._compression, device)
+        o = _EncoderOpts(int(opts._mode), opts._compression, device, int(opts._strategy), opts._mem_level)
         h = lib().chip_encoder_new(C.byref(o))
         return Encoder(h) if h else None
 

@@ -1048,9 +1048,18 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
                       void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
                       void *stream)
 {
+    return chip_encode_batch_ex(format, level, CHIP_STRATEGY_DEFAULT, n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, status, stream);
+}
+
+int chip_encode_batch_ex(int format, int level, int strategy, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                         void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len, int32_t *status,
+                         void *stream)
+{
     if (n == 0) return CHIP_OK;
+    if (level == -1) level = 6;  // zlib's Z_DEFAULT_COMPRESSION
     if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !status ||
-        level < 0 || level > 9 || (format != CHIP_FMT_DEFLATE && format != CHIP_FMT_ZLIB && format != CHIP_FMT_GZIP))
+        level < 0 || level > 9 || strategy < CHIP_STRATEGY_DEFAULT || strategy > CHIP_STRATEGY_FIXED ||
+        (format != CHIP_FMT_DEFLATE && format != CHIP_FMT_ZLIB && format != CHIP_FMT_GZIP))
         return CHIP_E_INVALID;
     if (!device_ok()) return CHIP_E_NO_DEVICE;
     BatchArgs a;
@@ -1069,7 +1078,7 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
     a.resume = nullptr;
     a.sel = nullptr;
     a.sel_n = nullptr;
-    hipError_t e = launch_deflate_l1(a, level, 7u, format == CHIP_FMT_ZLIB ? 1u : 0u, 0, nullptr, (hipStream_t)stream);
+    hipError_t e = launch_deflate_l1(a, level, 7u | ((uint32_t)strategy << 8), format == CHIP_FMT_ZLIB ? 1u : 0u, 0, nullptr, (hipStream_t)stream);
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }
 
@@ -1083,7 +1092,7 @@ int chip_encode_batch(int format, int level, size_t n, const void *in_base, cons
 
 struct chip_encoder {
     Hooks hooks;  // the allocator this object came from
-    int mode, level, device;
+    int mode, level, device, strategy;
     hipStream_t stream;
     uint8_t *h_in;  // pinned: input not yet compressed
     size_t h_in_cap, h_in_len;
@@ -1164,7 +1173,7 @@ bool enc_segment(chip_encoder *e, bool final)
     a.resume = nullptr;
     a.sel = nullptr;
     a.sel_n = nullptr;
-    const uint32_t flags = (e->started ? 0u : 1u) | (final ? 2u | 4u : 0u);
+    const uint32_t flags = (e->started ? 0u : 1u) | (final ? 2u | 4u : 0u) | ((uint32_t)e->strategy << 8);
     if (launch_deflate_l1(a, e->level, flags, e->check, e->total_in, &e->d_meta->check, e->stream) != hipSuccess) return false;
     if (hipMemcpyAsync(e->h_meta, e->d_meta, sizeof m, hipMemcpyDeviceToHost, e->stream) != hipSuccess) return false;
     if (hipStreamSynchronize(e->stream) != hipSuccess) return false;
@@ -1189,8 +1198,13 @@ extern "C" {
 
 chip_encoder *chip_encoder_new(const chip_encoder_opts *opts)
 {
+    // defaults of ZlibOptions::new(), src/encoder/zlib_common.rs:59-66
     int mode = opts ? opts->mode : CHIP_FMT_GZIP, level = opts ? opts->compression : 9;
+    const int strategy = opts ? opts->strategy : CHIP_STRATEGY_DEFAULT, mem_level = opts ? opts->mem_level : 0;
+    if (level == -1) level = 6;  // "Use -1 for zlib default" (zlib_common.rs:96-103): Z_DEFAULT_COMPRESSION
     if ((mode != CHIP_FMT_DEFLATE && mode != CHIP_FMT_ZLIB && mode != CHIP_FMT_GZIP) || level < 0 || level > 9) return nullptr;
+    // what deflateInit2_ refuses (Z_STREAM_ERROR -> None, src/encoder/zlib_ng.rs:81-86): memLevel outside 1..9, unknown strategy
+    if (strategy < CHIP_STRATEGY_DEFAULT || strategy > CHIP_STRATEGY_FIXED || mem_level < 0 || mem_level > 9) return nullptr;
     if (!device_ok()) return nullptr;  // no CPU codec behind this backend
     int device = opts ? opts->device : -1;
     if (device < 0 && hipGetDevice(&device) != hipSuccess) return nullptr;
@@ -1203,6 +1217,7 @@ chip_encoder *chip_encoder_new(const chip_encoder_opts *opts)
     e->hooks = hooks;
     e->mode = mode;
     e->level = level;
+    e->strategy = strategy;
     e->device = device;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) {
         hooks.release(e);

@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint
 struct EncArgs {
     BatchArgs b;
     int32_t level;
-    uint32_t flags;       // bit0 wrapper header, bit1 wrapper trailer, bit2 final block (else sync marker)
+    uint32_t flags;       // bit0 wrapper header, bit1 wrapper trailer, bit2 final block (else sync marker), [10:8] CHIP_STRATEGY_*
     uint32_t check_seed;  // running CRC-32 / Adler-32 of earlier segments of the same stream
     uint64_t total_before;  // bytes of earlier segments (gzip ISIZE)
     uint32_t *check_out;  // per unit: running check after this segment (may be null)
@@ -155,6 +155,8 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     uint8_t *gout = a.b.out_base + a.b.out_off[u];
     const uint32_t cap = a.b.out_cap[u];
     const bool hdr = a.flags & 1u, trl = a.flags & 2u, final = a.flags & 4u;
+    const uint32_t strategy = (a.flags >> 8) & 7u;
+    const bool no_match = strategy == CHIP_STRATEGY_HUFFMAN_ONLY, rle = strategy == CHIP_STRATEGY_RLE;
     const int fmt = a.b.format;
 
     const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);
@@ -215,6 +217,15 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
                 if (t && p - (t - 1) <= MAX_DIST) {
                     c.has = true;
                     c.q = t - 1;
+                }
+                // Z_RLE: the only candidate is the byte before (distance 1); Z_HUFFMAN_ONLY: none
+                if (rle) {
+                    c.has = p > 0;
+                    c.q = p > 0 ? p - 1 : p;
+                }
+                if (no_match) {
+                    c.has = false;
+                    c.q = p;
                 }
             }
             const uint32_t qi = (mis + c.q) >> 2, pi = (mis + p) >> 2;

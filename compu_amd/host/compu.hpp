@@ -180,10 +180,27 @@ struct Encode {
 
 using ZlibMode = decoder::ZlibMode;  // src/encoder/zlib_common.rs:28-37 (Deflate | Zlib | Gzip)
 
-// src/encoder/zlib_common.rs:47-103 (defaults: Gzip, compression 9, :59-66)
+// src/encoder/zlib_common.rs:5-24
+enum class ZlibStrategy { Default = 0, Filtered = 1, HuffmanOnly = 2, Rle = 3, Fixed = 4 };
+
+// src/encoder/zlib_common.rs:47-103 (defaults: Gzip, Default strategy, mem_level 8, compression 9, :59-66)
 struct ZlibOptions {
     ZlibMode mode_ = ZlibMode::Gzip;
+    ZlibStrategy strategy_ = ZlibStrategy::Default;
+    int mem_level_ = 8;
     int compression_ = 9;
+    ZlibOptions strategy(ZlibStrategy s) const
+    {
+        ZlibOptions o = *this;
+        o.strategy_ = s;
+        return o;
+    }
+    ZlibOptions mem_level(int level) const
+    {
+        ZlibOptions o = *this;
+        o.mem_level_ = level;
+        return o;
+    }
     ZlibOptions mode(ZlibMode m) const
     {
         ZlibOptions o = *this;
@@ -271,7 +288,7 @@ struct Interface {
     // Interface::zlib_ng(opts), src/encoder/zlib_ng.rs:50-87
     static std::optional<Encoder> zlib_hip(ZlibOptions opts = {}, int device = -1)
     {
-        chip_encoder_opts o{static_cast<int32_t>(opts.mode_), opts.compression_, device};
+        chip_encoder_opts o{static_cast<int32_t>(opts.mode_), opts.compression_, device, static_cast<int32_t>(opts.strategy_), opts.mem_level_};
         chip_encoder *h = chip_encoder_new(&o);
         if (!h) return std::nullopt;
         return Encoder(h);

@@ -202,12 +202,19 @@ int chip_detect_batch(size_t n, const void *in_base, const uint64_t *in_off, con
 
 typedef struct chip_encoder chip_encoder;
 
-/* ZlibOptions src/encoder/zlib_common.rs:47-66 (the two bytes compu replays on reset,
- * src/encoder/mod.rs:54,151,315, are {mode, compression}) */
+/* ZlibStrategy src/encoder/zlib_common.rs:5-24 (what zlib_ng.rs:69-75 hands to deflateInit2_) */
+enum { CHIP_STRATEGY_DEFAULT = 0, CHIP_STRATEGY_FILTERED = 1, CHIP_STRATEGY_HUFFMAN_ONLY = 2, CHIP_STRATEGY_RLE = 3, CHIP_STRATEGY_FIXED = 4 };
+
+/* ZlibOptions src/encoder/zlib_common.rs:47-103, every field (zlib-ng keeps them in its state and ignores the two
+ * bytes compu replays on reset: src/encoder/zlib_ng.rs:84,95) */
 typedef struct {
     int32_t mode;        /* CHIP_FMT_DEFLATE | CHIP_FMT_ZLIB | CHIP_FMT_GZIP (default Gzip, zlib_common.rs:33-37) */
-    int32_t compression; /* 0..9; this backend implements the level-1 class (greedy match + fixed Huffman) for 1..9 */
-    int32_t device;
+    int32_t compression; /* 0..9, or -1 = zlib's default (6) as zlib_common.rs:96-103 allows; this backend implements the
+                          * level-1 class (greedy match + fixed Huffman) for every level >= 1 */
+    int32_t device;      /* HIP device ordinal, -1 = current */
+    int32_t strategy;    /* CHIP_STRATEGY_*: HuffmanOnly emits no matches, Rle only distance-1 matches; Default, Filtered
+                          * and Fixed are the same here (the level-1 class always uses the fixed code) */
+    int32_t mem_level;   /* 1..9 (zlib's memLevel; 0 = default 8): accepted for compatibility, the GPU state has one size */
 } chip_encoder_opts;
 
 /* Interface::zlib_ng(opts) src/encoder/zlib_ng.rs:50-87 */
@@ -218,6 +225,11 @@ chip_encode_result chip_encode(chip_encoder *e, const uint8_t *in, size_t in_len
 chip_encoder *chip_encoder_reset(chip_encoder *e);
 /* drop_fn src/encoder/zlib_ng.rs:107-111 */
 void chip_encoder_free(chip_encoder *e);
+
+/* chip_encode_batch with a strategy (CHIP_STRATEGY_*); chip_encode_batch is strategy Default. */
+int chip_encode_batch_ex(int format, int level, int strategy, size_t n, const void *in_base, const uint64_t *in_off,
+                         const uint32_t *in_len, void *out_base, const uint64_t *out_off, const uint32_t *out_cap,
+                         uint32_t *out_len, int32_t *status, void *stream);
 
 /* Batched level-1 encode of n independent units (device pointers, one wavefront per unit).
  * out_len[i] = compressed size; status[i] = CHIP_ENC_FINISHED or CHIP_ENC_NEED_OUTPUT.  Each unit becomes

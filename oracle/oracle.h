@@ -98,6 +98,7 @@ typedef struct {
 typedef struct orc_deflate orc_deflate;
 /* Interface::zlib_ng(opts), src/encoder/zlib_ng.rs:50-87; mode = -15 | 15 | 31 */
 orc_deflate *orc_deflate_new(int mode, int level);
+int orc_deflate_set_strategy(orc_deflate *s, int strategy); /* ZlibStrategy 0..4, default 0 */
 /* encode_fn, src/encoder/zlib_ng.rs:90-92 + internal_zlib_impl_encode! src/encoder/mod.rs:334-370 */
 orc_encode_t orc_deflate_encode(orc_deflate *s, const uint8_t *in, size_t in_len, uint8_t *out, size_t out_len, int op);
 void orc_deflate_reset(orc_deflate *s);

@@ -79,6 +79,7 @@ def lib():
             L.orc_deflate_new.argtypes = [C.c_int, C.c_int]
             L.orc_deflate_encode.restype = EncodeT
             L.orc_deflate_encode.argtypes = [C.c_void_p, u8p, C.c_size_t, u8p, C.c_size_t, C.c_int]
+            L.orc_deflate_set_strategy.argtypes = [C.c_void_p, C.c_int]
             L.orc_deflate_reset.argtypes = [C.c_void_p]
             L.orc_deflate_free.argtypes = [C.c_void_p]
         _lib = L
@@ -143,10 +144,12 @@ class ZstdDecoder(_StreamDecoder):
 class DeflateEncoder:
     """Shape of compu's Encoder (src/encoder/mod.rs:148-323) over the oracle deflater."""
 
-    def __init__(self, mode=MODE_GZIP, level=1):
+    def __init__(self, mode=MODE_GZIP, level=1, strategy=0):
         self._h = lib().orc_deflate_new(mode, level)
         if not self._h:
             raise MemoryError("oracle encoder construction failed")
+        if lib().orc_deflate_set_strategy(self._h, strategy) != 0:
+            raise ValueError("bad strategy")
 
     def encode(self, data, out_len, op):
         src = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, np.uint8)

@@ -91,7 +91,7 @@ static size_t stored_size(size_t n, int sync)
 /* One byte-aligned deflate segment for in[0..n): fixed-Huffman block (or stored blocks when not
  * larger), closed by the final-block flag (final) or by a sync marker (!final).  Returns the size;
  * *overflow is set when cap was too small. */
-static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int level, int final, int *overflow)
+static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int level, int strategy, int final, int *overflow)
 {
     bitw w = {out, cap, 0, 0, 0, 0};
     size_t ssz = stored_size(n, !final);
@@ -112,6 +112,9 @@ static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t c
                 uint32_t h = (v * 2654435761u) >> (32 - HASH_BITS);
                 hh[l] = h;
                 uint32_t c = table[h];
+                /* strategy 3 (Z_RLE): the only candidate is the byte before; 2 (Z_HUFFMAN_ONLY): none */
+                if (strategy == 3) c = p > 0 ? (uint32_t)p : 0;
+                if (strategy == 2) c = 0;
                 if (c && p - (c - 1) <= MAX_DIST) {
                     size_t q = c - 1, lim = n - p < MAX_MATCH ? n - p : MAX_MATCH, k = 0;
                     while (k < lim && in[q + k] == in[p + k]) k++;
@@ -158,7 +161,7 @@ static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t c
 }
 
 struct orc_deflate {
-    int mode, level;
+    int mode, level, strategy;
     uint8_t *in; size_t in_len, in_cap;    /* input not yet compressed */
     uint8_t *out; size_t out_len, out_cap, delivered;
     int started, finished;
@@ -175,6 +178,14 @@ orc_deflate *orc_deflate_new(int mode, int level)
     s->level = level;
     orc_deflate_reset(s);
     return s;
+}
+
+/* ZlibStrategy (src/encoder/zlib_common.rs:5-24): 0 Default, 1 Filtered, 2 HuffmanOnly, 3 Rle, 4 Fixed */
+int orc_deflate_set_strategy(orc_deflate *s, int strategy)
+{
+    if (!s || strategy < 0 || strategy > 4) return -1;
+    s->strategy = strategy;
+    return 0;
 }
 
 void orc_deflate_reset(orc_deflate *s)
@@ -244,7 +255,7 @@ orc_encode_t orc_deflate_encode(orc_deflate *s, const uint8_t *in, size_t in_len
         int final = op == ORC_OP_FINISH, ovf = 0;
         size_t bound = stored_size(s->in_len, !final) + 16;
         dgrow(&s->out, &s->out_cap, s->out_len + bound);
-        s->out_len += encode_segment(s->in, s->in_len, s->out + s->out_len, bound, s->level, final, &ovf);
+        s->out_len += encode_segment(s->in, s->in_len, s->out + s->out_len, bound, s->level, s->strategy, final, &ovf);
         if (s->mode == ORC_MODE_GZIP) s->check = orc_crc32(s->check, s->in, s->in_len);
         else if (s->mode == ORC_MODE_ZLIB) s->check = orc_adler32(s->check, s->in, s->in_len);
         s->total_in += s->in_len;

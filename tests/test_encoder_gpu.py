@@ -222,3 +222,42 @@ def test_host_memory_encode_matches_the_oracle(gpu):
         enc = O.DeflateEncoder(O.MODE_GZIP, 1)
         ref, in_rem, out_rem, est = enc.encode(d, int(caps[i]), O.OP_FINISH)
         assert got == ref, i
+
+
+def test_zlib_options_surface_strategy_mem_level_default_level(gpu, alice):
+    """Every field of ZlibOptions (src/encoder/zlib_common.rs:47-103) reaches the backend as deflateInit2_ would get it
+    (src/encoder/zlib_ng.rs:69-79): strategy (HuffmanOnly: no matches, Rle: distance 1 only), mem_level 1..9,
+    compression -1 = zlib's default; what zlib refuses (Z_STREAM_ERROR -> None) is refused.  GPU bytes == oracle bytes."""
+    import compu_amd
+    from compu_amd import ZlibMode, ZlibOptions, ZlibStrategy, EncodeOp, EncodeStatus
+    from oracle import oracle as O
+
+    runs = bytes([7]) * 5000 + alice[:20000] + b"ab" * 3000 + bytes(range(256)) * 8
+    for strat in ZlibStrategy:
+        for level in (-1, 1, 9):
+            enc = compu_amd.encoder_interface.zlib_hip(ZlibOptions().mode(ZlibMode.Zlib).compression(level).strategy(strat).mem_level(9 if level == 9 else 1))
+            assert enc is not None
+            out = compu_amd.Vec(0)
+            r = enc.encode_vec_full(runs, out, EncodeOp.Finish)
+            assert r.status == EncodeStatus.Finished
+            comp = bytes(out)
+            assert zlib.decompress(comp) == runs
+            ref = O.DeflateEncoder(O.MODE_ZLIB, 6 if level == -1 else level, int(strat))
+            want, _ir, _or, st = ref.encode(runs, len(runs) + 1024, 2)
+            assert st == 2 and comp == want, (strat, level)
+        # what the strategy means, seen from the decoder: tokens of the fixed-Huffman stream
+    sizes = {}
+    for strat in ZlibStrategy:
+        enc = compu_amd.encoder_interface.zlib_hip(ZlibOptions().mode(ZlibMode.Deflate).compression(1).strategy(strat))
+        out = compu_amd.Vec(0)
+        enc.encode_vec_full(runs, out, EncodeOp.Finish)
+        sizes[strat] = len(bytes(out))
+    assert sizes[ZlibStrategy.Default] == sizes[ZlibStrategy.Filtered] == sizes[ZlibStrategy.Fixed]
+    assert sizes[ZlibStrategy.HuffmanOnly] > sizes[ZlibStrategy.Rle] > sizes[ZlibStrategy.Default]  # no matches > runs only > all matches
+    # refused like deflateInit2_ refuses them
+    L = compu_amd.lib()
+    from compu_amd.api import _EncoderOpts
+    import ctypes as C
+
+    for bad in (_EncoderOpts(31, 1, -1, 5, 8), _EncoderOpts(31, 1, -1, 0, 10), _EncoderOpts(31, 10, -1, 0, 8), _EncoderOpts(31, -2, -1, 0, 8), _EncoderOpts(47, 1, -1, 0, 8)):
+        assert not L.chip_encoder_new(C.byref(bad))
