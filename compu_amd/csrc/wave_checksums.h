@@ -38,7 +38,9 @@ __device__ __forceinline__ void lane_chunk(uint32_t n, uint32_t &chunk_log2, uin
     beg = b > 0 ? (uint32_t)b : 0u;
 }
 
-// CRC-32 (RFC 1952 sec. 8) of p[0..n).  `tab` is 256 words of LDS scratch.
+// CRC-32 (RFC 1952 sec. 8) of p[0..n).  `tab` is 2048 words (8 KB) of LDS scratch: eight 256-entry tables
+// (slicing by 8: table k advances the register over a byte that lies k bytes further on).  A lane runs over its chunk
+// with aligned 16-byte loads, eight bytes per dependent step; the chunks' registers are then combined across lanes.
 __device__ inline uint32_t wave_crc32(uint32_t *tab, const uint8_t *p, uint32_t n, uint32_t seed = 0)
 {
     const uint32_t lane = lane_id();
@@ -50,38 +52,79 @@ __device__ inline uint32_t wave_crc32(uint32_t *tab, const uint8_t *p, uint32_t 
         tab[i] = c;
     }
     WSYNC();
+    for (uint32_t k = 1; k < 8; k++) {
+        for (uint32_t i = lane; i < 256; i += 64) {
+            const uint32_t c = tab[(k - 1) * 256 + i];
+            tab[k * 256 + i] = (c >> 8) ^ tab[c & 0xffu];
+        }
+        WSYNC();
+    }
     uint32_t lg, beg, end;
     lane_chunk(n, lg, beg, end);
     uint32_t c = (beg == 0 && end > 0) ? ~seed : 0u;  // the lane that owns byte 0 carries the running value
     if (n == 0 && lane == 63) c = ~seed;
-    for (uint32_t k = beg; k < end; k++) c = tab[(c ^ p[k]) & 0xffu] ^ (c >> 8);
+    uint32_t k = beg;
+    // bytes up to a 16-byte boundary of the address
+    while (k < end && (((uintptr_t)(p + k)) & 15u) != 0) {
+        c = tab[(c ^ p[k]) & 0xffu] ^ (c >> 8);
+        k++;
+    }
+    // 16 bytes per load, two steps of eight bytes
+    for (; k + 16 <= end; k += 16) {
+        const uint4 d = *(const uint4 *)(p + k);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t lo = (h ? d.z : d.x) ^ c, hi = h ? d.w : d.y;
+            c = tab[7 * 256 + (lo & 0xffu)] ^ tab[6 * 256 + ((lo >> 8) & 0xffu)] ^ tab[5 * 256 + ((lo >> 16) & 0xffu)] ^ tab[4 * 256 + (lo >> 24)] ^
+                tab[3 * 256 + (hi & 0xffu)] ^ tab[2 * 256 + ((hi >> 8) & 0xffu)] ^ tab[1 * 256 + ((hi >> 16) & 0xffu)] ^ tab[hi >> 24];
+        }
+    }
+    for (; k < end; k++) c = tab[(c ^ p[k]) & 0xffu] ^ (c >> 8);
     // tree combine: state(A||B) = state(A) * x^(8|B|) + raw(B); right blocks have 2^k * chunk bytes
 #pragma unroll
-    for (int k = 0; k < 6; k++) {
-        uint32_t left = (uint32_t)__shfl_up((int)c, 1 << k, 64);
-        uint32_t f = X2N[(3 + lg + k) & 31];
+    for (int k2 = 0; k2 < 6; k2++) {
+        uint32_t left = (uint32_t)__shfl_up((int)c, 1 << k2, 64);
+        uint32_t f = X2N[(3 + lg + k2) & 31];
         uint32_t comb = multmodp(f, left) ^ c;
-        if ((lane & ((2u << k) - 1)) == ((2u << k) - 1)) c = comb;
+        if ((lane & ((2u << k2) - 1)) == ((2u << k2) - 1)) c = comb;
     }
     WSYNC();
     return ~rdlane(c, 63);
 }
 
-// Adler-32 (RFC 1950 sec. 9) of p[0..n)
+// Adler-32 (RFC 1950 sec. 9) of p[0..n): per lane chunk sums (16 bytes per load), then the weighted combination
 __device__ inline uint32_t wave_adler32(const uint8_t *p, uint32_t n, uint32_t seed = 1)
 {
     uint32_t lg, beg, end;
     lane_chunk(n, lg, beg, end);
     uint32_t a = 0, b = 0, k = beg;
-    while (k < end) {
-        uint32_t stop = end - k > 2048 ? k + 2048 : end;
-        for (; k < stop; k++) {
-            a += p[k];
-            b += a;
+    while (k < end && (((uintptr_t)(p + k)) & 15u) != 0) {
+        a += p[k];
+        b += a;
+        k++;
+    }
+    while (k + 16 <= end) {
+        // at most 2048 bytes between reductions: b grows by less than 2048 * (a + 255 * 2048) < 2^32 with a, b < 65521
+        const uint32_t stop = end - k > 2048 ? k + 2048 : k + ((end - k) & ~15u);
+        for (; k < stop; k += 16) {
+            const uint4 d = *(const uint4 *)(p + k);
+            const uint32_t w[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t b0 = w[j] & 0xffu, b1 = (w[j] >> 8) & 0xffu, b2 = (w[j] >> 16) & 0xffu, b3 = w[j] >> 24;
+                b += 4u * a + 4u * b0 + 3u * b1 + 2u * b2 + b3;
+                a += b0 + b1 + b2 + b3;
+            }
         }
         a %= 65521u;
         b %= 65521u;
     }
+    for (; k < end; k++) {
+        a += p[k];
+        b += a;
+    }
+    a %= 65521u;
+    b %= 65521u;
     // B_total = sum_i (b_i + a_i * bytes_after_i) + n ; A_total = 1 + sum a_i
     uint64_t after = (uint64_t)(n - end);
     uint32_t term = (uint32_t)(((uint64_t)b + (uint64_t)a * (after % 65521u)) % 65521u);

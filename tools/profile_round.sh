@@ -1,14 +1,26 @@
 #!/bin/bash
 # Round profile recipe (GPU box): kernel trace of the default bench, then FETCH_SIZE / WRITE_SIZE in their own
-# passes (never combined with other trace domains).  Outputs land under gpurun_out/; tools/profiles_summarize.py
-# turns them into the files kept under profiles/.   usage: bash tools/profile_round.sh <tag>
+# passes (never combined with other trace domains) -- for the default (dynamic-Huffman) workload, whose run also covers
+# the stored and fixed variants, and for the mixed gzip+zstd (chip::zstd_kernel) and encode (chip::deflate_kernel)
+# workloads.  Outputs land under gpurun_out/; tools/profiles_summarize.py turns them into the files kept under profiles/.
+#   usage: bash tools/profile_round.sh <tag>
 set -eo pipefail
-tag="${1:-r01}"
+tag="${1:-r02}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 make -s -C oracle
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kt -o run --output-format csv -- python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.log
+echo "[profile] default bench traced"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_pmc_fetch -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> gpurun_out/${tag}_pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_pmc_write -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> gpurun_out/${tag}_pmc_write.log
-python3 bench.py --workload mixed --no-cpu > gpurun_out/${tag}_mixed.json 2>> gpurun_out/${tag}_bench.log
-python3 bench.py --workload encode --no-cpu > gpurun_out/${tag}_encode.json 2>> gpurun_out/${tag}_bench.log
+echo "[profile] default PMC passes done"
+for wl in mixed encode; do
+  rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_${wl}_kt -o run --output-format csv -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu --extra 0 > gpurun_out/${tag}_${wl}.json 2>> gpurun_out/${tag}_bench.log
+  echo "[profile] $wl traced"
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_${wl}_pmc_fetch -o run --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --extra 0 > /dev/null 2>> gpurun_out/${tag}_bench.log
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_${wl}_pmc_write -o run --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --extra 0 > /dev/null 2>> gpurun_out/${tag}_bench.log
+  echo "[profile] $wl PMC passes done"
+done
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d gpurun_out/${tag}_pmc_insts -o run --output-format csv -- python3 tools/prof_run.py dynamic 8192 3 > gpurun_out/${tag}_pmc_insts.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_insts/run_counter_collection.csv 8192 > gpurun_out/${tag}_pmc_insts.txt || true
+echo "[profile] done"

@@ -3,7 +3,7 @@ python tools/profiles_summarize.py <tag>   (run in the dev container after the g
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -50,6 +50,40 @@ for wl, t in traffic.items():
     rd, wr = int(t["fetch"] * 1024 * 2), int(t["write"] * 1024)
     out[wl] = {"fetch_size_kib_raw": t["fetch"], "write_size_kib": t["write"], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
 json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+# 4. the mixed (gzip + zstd) and encode workloads: kernel stats and traffic of their kernels
+def _avg_counter(path_glob, kernel, ctr):
+    rr = [r for r in csv.DictReader(open(one(path_glob))) if kernel in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+    rr.sort(key=lambda r: int(r["Dispatch_Id"]))
+    vals = [float(r["Counter_Value"]) for r in rr[1:]] or [float(r["Counter_Value"]) for r in rr]  # drop the warm-up dispatch
+    return rr, (sum(vals) / len(vals) if vals else 0.0)
+
+
+for wl, kernels in (("mixed", ("inflate_kernel", "zstd_kernel")), ("encode", ("deflate_kernel",))):
+    try:
+        with open(one(f"{tag}_{wl}_kt/**/*kernel_stats.csv")) as f, open(os.path.join(P, f"{tag}_{wl}_kernel_stats.csv"), "w") as o:
+            o.write(f.read())
+        tot = {"fetch": 0.0, "write": 0.0}
+        per = {}
+        for name, ctr in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+            keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"]
+            allrows = []
+            for k in kernels:
+                rr, avg = _avg_counter(f"{tag}_{wl}_pmc_{name}/**/*counter_collection.csv", k, ctr)
+                allrows += rr
+                tot[name] += avg
+                per.setdefault(k, {})[name] = avg
+            with open(os.path.join(P, f"{tag}_{wl}_pmc_{name}_size.csv"), "w") as o:
+                w = csv.DictWriter(o, keep, extrasaction="ignore")
+                w.writeheader()
+                w.writerows(allrows)
+        rd, wr = int(tot["fetch"] * 1024 * 2), int(tot["write"] * 1024)
+        out[wl] = {"fetch_size_kib_raw": tot["fetch"], "write_size_kib": tot["write"], "hbm_read_bytes": rd, "hbm_write_bytes": wr,
+                   "hbm_bytes_per_launch": rd + wr, "per_kernel_kib": per}
+    except SystemExit as e:
+        print("skipped", wl, e)
+json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
+if os.path.exists(os.path.join(G, f"{tag}_pmc_insts.txt")):
+    open(os.path.join(P, f"{tag}_pmc_insts.txt"), "w").write(open(os.path.join(G, f"{tag}_pmc_insts.txt")).read())
 for src, dst in ((f"{tag}_bench.json", f"{tag}_bench_rocprof_run.json"), (f"{tag}_mixed.json", f"{tag}_bench_mixed.json"), (f"{tag}_encode.json", f"{tag}_bench_encode.json")):
     if os.path.exists(os.path.join(G, src)):
         open(os.path.join(P, dst), "w").write(open(os.path.join(G, src)).read())
