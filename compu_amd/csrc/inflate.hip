@@ -88,7 +88,7 @@ constexpr int XT_BITS = CHIP_XT_BITS;
 #endif
 constexpr int XT_BITS_FIXED = CHIP_XT_BITS_FIXED;
 constexpr int ROW_TOKENS = CHIP_ROW_TOKENS;
-static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0, "geometry");
+static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0 && 64 * ROW_TOKENS < 65536, "geometry");
 constexpr int ROW_WORDS = S_BITS / 32;  // boundary bitmap words per lane (own segment only)
 // x / S_BITS for x < 2^15 (bit offsets inside a super-round) as a multiply and a shift
 constexpr uint32_t SEG_SHIFT = 22;
@@ -103,6 +103,12 @@ static_assert(seg_magic_ok() && (64u * S_BITS + 4096u) * (uint64_t)SEG_MAGIC < (
 constexpr int IN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
 static_assert(IN_DW >= 320, "table-build scratch lives in the input window");
 constexpr size_t SCRATCH_WORDS_PER_WAVE = (size_t)64 * ROW_TOKENS;
+// Layout of a wave's token scratch: a 128-byte line holds four tokens (one 16-byte store) of each of eight neighbouring
+// lanes, so that one store instruction of the walk fills whole lines (lane l, row token k = 4q + j -> word
+// rowbase(l) + 32 q + j with rowbase(l) = (l / 8) * 8 * ROW_TOKENS + (l % 8) * 4).  With a row per lane (round 1) the 64
+// lanes of a store hit 64 different lines with 16 bytes each; doubling those stores cost +32 % kernel time.
+__device__ __forceinline__ uint32_t row_base(uint32_t l) { return (l >> 3) * (8u * ROW_TOKENS) + (l & 7u) * 4u; }
+__device__ __forceinline__ uint32_t row_word(uint32_t k) { return k + (k >> 2) * 28u; }  // 32 * (k / 4) + k % 4
 
 // token: [8:0] match length (0 = literal), [31:9] literal byte or match distance
 __device__ __forceinline__ uint32_t tok_lit(uint32_t b) { return b << 9; }
@@ -130,7 +136,7 @@ struct alignas(16) WaveLds {
             uint8_t lens[320];
         } hdr;
     };
-    uint32_t pk[128];       // k-th piece of the true stream: [2k] its first stream index, [2k+1] scratch word index of its first token minus that
+    uint32_t pk[128];       // k-th piece of the true stream: [2k] its first stream index, [2k+1] [15:0] (row token - stream index) mod 2^16, [31:16] row base
     HuffMeta lit_h, dist_h;
     uint32_t use_sub;  // long codes resolve through sub-tables living in lit_sorted/dist_sorted
 };
@@ -646,7 +652,8 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         t = t < ntok ? t : ntok - 1u;
         before += inside;
         gnext = g + 64u;
-        const uint32_t *src = grow + (t + d);
+        const uint32_t krow = (t + d) & 0xffffu;  // the token's index in its lane's row
+        const uint32_t *src = grow + ((d >> 16) + row_word(krow));
         const uint32_t dst = tok_lds + 256u * slot_w;
         uint32_t keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -802,7 +809,7 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
     pos = rdfirst(pos);
     opos = rdfirst(opos);
     const bool use_sub = rdfirst(L.use_sub) != 0;
-    uint32_t *const myrow = grow + lane * ROW_TOKENS;
+    uint32_t *const myrow = grow + row_base(lane);
     for (;;) {
         const uint32_t B = pos;
         if (B >= end_bit) {
@@ -869,7 +876,7 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                 active = go && p < lim && nst < (uint32_t)ROW_TOKENS;
                 if (go && !active) aux = p;  // reason stays R_LIMIT: the chain simply ends here
             }
-            if (was && nst > q0) *(uint4 *)(myrow + q0) = make_uint4(t4[0], t4[1], t4[2], t4[3]);
+            if (was && nst > q0) *(uint4 *)(myrow + 8u * q0) = make_uint4(t4[0], t4[1], t4[2], t4[3]);  // q0 is a multiple of 4: row_word(q0)
         }
         WSYNC();  // rows complete; token stores have landed (the barrier's release waits for them)
         STAT_ACC(2);
@@ -916,7 +923,7 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         if (cnt) {
             const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt()), first = incl - cnt;
             L.pk[2u * k] = first;
-            L.pk[2u * k + 1u] = lane * ROW_TOKENS + a0 - first;
+            L.pk[2u * k + 1u] = ((a0 - first) & 0xffffu) | (row_base(lane) << 16);  // row token = stream index + (a0 - first)
         }
         WSYNC();
         STAT_ACC(3);
