@@ -88,52 +88,280 @@ static size_t stored_size(size_t n, int sync)
     return n + 5 * blocks + (sync ? 5 : 0);
 }
 
-/* One byte-aligned deflate segment for in[0..n): fixed-Huffman block (or stored blocks when not
- * larger), closed by the final-block flag (final) or by a sync marker (!final).  Returns the size;
- * *overflow is set when cap was too small. */
+/* ---- the match finder: one 64-position chunk -> tokens ---------------------------------------- */
+typedef struct { uint32_t table[1u << HASH_BITS]; size_t skip; } matcher;
+
+#define TOK_MATCH 0x80000000u
+#define TOK_LEN(t) (((t) & 0xffu) + 3u)
+#define TOK_DIST(t) ((((t) >> 9) & 0x7fffu) + 1u)
+
+/* Greedy tokens of the chunk [base, base+64) of in[0..n), appended to tok (a literal is its byte, a match
+ * TOK_MATCH | (dist-1) << 9 | (len-3)); a match may run past the chunk, m->skip carries the overrun. */
+static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t base, int strategy, uint32_t *tok)
+{
+    unsigned mlen[64], mdist[64], nt = 0;
+    uint32_t hh[64];
+    uint32_t *table = m->table;
+    for (unsigned l = 0; l < 64; l++) {
+        size_t p = base + l;
+        mlen[l] = 0;
+        mdist[l] = 0;
+        hh[l] = 0xffffffffu;
+        if (p + 4 > n) continue;
+        uint32_t v = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
+        uint32_t h = (v * 2654435761u) >> (32 - HASH_BITS);
+        hh[l] = h;
+        uint32_t c = table[h];
+        /* strategy 3 (Z_RLE): the only candidate is the byte before; 2 (Z_HUFFMAN_ONLY): none */
+        if (strategy == 3) c = p > 0 ? (uint32_t)p : 0;
+        if (strategy == 2) c = 0;
+        if (c && p - (c - 1) <= MAX_DIST) {
+            size_t q = c - 1, lim = n - p < MAX_MATCH ? n - p : MAX_MATCH, k = 0;
+            while (k < lim && in[q + k] == in[p + k]) k++;
+            if (k >= MIN_MATCH) { mlen[l] = (unsigned)k; mdist[l] = (unsigned)(p - q); }
+        }
+    }
+    for (unsigned l = 0; l < 64; l++)
+        if (hh[l] != 0xffffffffu && table[hh[l]] < base + l + 1) table[hh[l]] = (uint32_t)(base + l + 1);
+    size_t pos = m->skip;
+    while (pos < 64 && base + pos < n) {
+        if (mlen[pos] >= MIN_MATCH) { tok[nt++] = TOK_MATCH | ((mdist[pos] - 1) << 9) | (mlen[pos] - 3); pos += mlen[pos]; }
+        else { tok[nt++] = in[base + pos]; pos += 1; }
+    }
+    m->skip = pos > 64 ? pos - 64 : 0;
+    return nt;
+}
+
+/* ---- dynamic Huffman blocks (levels 2..9) ------------------------------------------------------
+ * Blocks close after TOK_BLOCK - 64 tokens or more (zlib's lit_bufsize at memLevel 8 is the same 16384).
+ * Code lengths: plain Huffman over (frequency, symbol)-sorted leaves with the two-queue method (ties
+ * take the leaf); when the deepest leaf exceeds the limit every frequency is halved (rounding up)
+ * and the tree rebuilt.  Canonical codes and the code-length header follow RFC 1951 sec. 3.2.2 / 3.2.7
+ * with a greedy run-length pass.  Per block the cheapest of dynamic, fixed and stored is written. */
+#define TOK_BLOCK 16384u
+static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+static void build_lengths(const uint32_t *freq_in, int n, int maxbits, uint8_t *len)
+{
+    uint32_t freq[288], key[288], w[576];
+    uint16_t parent[576];
+    int m = 0;
+    for (int i = 0; i < n; i++) { freq[i] = freq_in[i]; len[i] = 0; if (freq[i]) m++; }
+    if (m == 0) return;
+    if (m == 1) { for (int i = 0; i < n; i++) if (freq[i]) len[i] = 1; return; }
+    for (;;) {
+        /* leaves by (frequency, symbol) */
+        int k = 0;
+        for (int i = 0; i < n; i++) if (freq[i]) key[k++] = (freq[i] << 9) | (uint32_t)i;
+        for (int i = 1; i < m; i++) { uint32_t x = key[i]; int j = i; while (j > 0 && key[j - 1] > x) { key[j] = key[j - 1]; j--; } key[j] = x; }
+        for (int i = 0; i < m; i++) w[i] = key[i] >> 9;
+        int li = 0, ii = m, nn = m;
+        while (nn < 2 * m - 1) {
+            int a = (li < m && (ii >= nn || w[li] <= w[ii])) ? li++ : ii++;
+            int b = (li < m && (ii >= nn || w[li] <= w[ii])) ? li++ : ii++;
+            w[nn] = w[a] + w[b];
+            parent[a] = parent[b] = (uint16_t)nn;
+            nn++;
+        }
+        /* depth replaces weight, root first */
+        w[2 * m - 2] = 0;
+        unsigned deepest = 0;
+        for (int i = 2 * m - 3; i >= 0; i--) { w[i] = w[parent[i]] + 1; if (i < m && w[i] > deepest) deepest = w[i]; }
+        if (deepest <= (unsigned)maxbits) {
+            for (int i = 0; i < m; i++) len[key[i] & 511u] = (uint8_t)w[i];
+            return;
+        }
+        for (int i = 0; i < n; i++) if (freq[i]) freq[i] = (freq[i] + 1) >> 1;
+    }
+}
+
+/* canonical codes (RFC 1951 sec. 3.2.2), stored bit-reversed for the LSB-first writer */
+static void canon_codes(const uint8_t *len, int n, uint16_t *code)
+{
+    unsigned count[16] = {0}, next[16];
+    for (int i = 0; i < n; i++) count[len[i]]++;
+    count[0] = 0;
+    unsigned c = 0;
+    for (int b = 1; b < 16; b++) { c = (c + count[b - 1]) << 1; next[b] = c; }
+    for (int i = 0; i < n; i++) code[i] = len[i] ? (uint16_t)rev(next[len[i]]++, len[i]) : 0;
+}
+
+static int len_code(unsigned len) { int lc = 28; while (LBASE[lc] > len) lc--; return lc; }
+static int dist_code(unsigned dist) { int dc = 29; while (DBASE[dc] > dist) dc--; return dc; }
+
+static void fixed_lengths(uint8_t *ll, uint8_t *dl)
+{
+    for (int i = 0; i < 288; i++) ll[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
+    for (int i = 0; i < 30; i++) dl[i] = 5;
+}
+
+/* stored form of `len` bytes written at bit position `at` of the stream: bits */
+static uint64_t stored_bits(uint64_t at, size_t len)
+{
+    uint64_t p = at;
+    size_t off = 0;
+    do {
+        size_t k = len - off < 65535 ? len - off : 65535;
+        p += 3;
+        p = (p + 7) & ~(uint64_t)7;
+        p += 32 + 8 * (uint64_t)k;
+        off += k;
+    } while (off < len);
+    return p - at;
+}
+
+/* One block: tokens tok[0..nt) covering in[from..to), `last` = BFINAL. */
+static void write_block(bitw *w, const uint32_t *tok, unsigned nt, const uint8_t *in, size_t from, size_t to, int last)
+{
+    uint32_t lfreq[288] = {0}, dfreq[32] = {0};
+    uint64_t xbits = 0, nmatch = 0;
+    for (unsigned i = 0; i < nt; i++) {
+        if (tok[i] & TOK_MATCH) {
+            int lc = len_code(TOK_LEN(tok[i])), dc = dist_code(TOK_DIST(tok[i]));
+            lfreq[257 + lc]++;
+            dfreq[dc]++;
+            xbits += LEXT[lc] + DEXT[dc];
+            nmatch++;
+        } else lfreq[tok[i]]++;
+    }
+    lfreq[256]++;
+    uint8_t ll[288], dl[32], fl[288], fd[32];
+    build_lengths(lfreq, 286, 15, ll);
+    ll[286] = ll[287] = 0;
+    build_lengths(dfreq, 30, 15, dl);
+    if (!nmatch) dl[0] = 1; /* one distance code is always described */
+    int hlit = 286, hdist = 30;
+    while (hlit > 257 && !ll[hlit - 1]) hlit--;
+    while (hdist > 1 && !dl[hdist - 1]) hdist--;
+    /* code-length sequence, greedy runs */
+    uint8_t all[320];
+    uint16_t seq[320]; /* symbol | extra << 8 */
+    int na = 0, ns = 0;
+    for (int i = 0; i < hlit; i++) all[na++] = ll[i];
+    for (int i = 0; i < hdist; i++) all[na++] = dl[i];
+    uint32_t cfreq[19] = {0};
+    uint64_t cl_extra = 0;
+    for (int i = 0; i < na;) {
+        int v = all[i], run = 1;
+        while (i + run < na && all[i + run] == v) run++;
+        i += run;
+        if (v == 0) {
+            while (run >= 11) { int r = run < 138 ? run : 138; seq[ns++] = (uint16_t)(18 | ((r - 11) << 8)); cl_extra += 7; run -= r; }
+            if (run >= 3) { seq[ns++] = (uint16_t)(17 | ((run - 3) << 8)); cl_extra += 3; run = 0; }
+            while (run-- > 0) seq[ns++] = 0;
+        } else {
+            seq[ns++] = (uint16_t)v;
+            run--;
+            while (run >= 3) { int r = run < 6 ? run : 6; seq[ns++] = (uint16_t)(16 | ((r - 3) << 8)); cl_extra += 2; run -= r; }
+            while (run-- > 0) seq[ns++] = (uint16_t)v;
+        }
+    }
+    for (int i = 0; i < ns; i++) cfreq[seq[i] & 0xff]++;
+    uint8_t cl[19];
+    build_lengths(cfreq, 19, 7, cl);
+    int hclen = 19;
+    while (hclen > 4 && !cl[CL_ORDER[hclen - 1]]) hclen--;
+    /* costs */
+    fixed_lengths(fl, fd);
+    uint64_t dyn = 3 + 14 + 3 * (uint64_t)hclen + cl_extra + xbits, fix = 3 + xbits;
+    for (int i = 0; i < 19; i++) dyn += (uint64_t)cfreq[i] * cl[i];
+    for (int i = 0; i < 286; i++) { dyn += (uint64_t)lfreq[i] * ll[i]; fix += (uint64_t)lfreq[i] * fl[i]; }
+    for (int i = 0; i < 30; i++) { dyn += (uint64_t)dfreq[i] * dl[i]; fix += (uint64_t)dfreq[i] * fd[i]; }
+    const int use_dyn = dyn < fix;
+    const uint64_t huff = use_dyn ? dyn : fix, at = (uint64_t)w->len * 8 + (uint64_t)w->nacc;
+    if (stored_bits(at, to - from) < huff) {
+        size_t off = from;
+        do {
+            size_t k = to - off < 65535 ? to - off : 65535;
+            bw_put(w, (uint32_t)(last && off + k == to), 3);
+            bw_align(w);
+            bw_put(w, (uint32_t)k | ((uint32_t)(~k & 0xffff) << 16), 32);
+            for (size_t i = 0; i < k; i++) bw_put(w, in[off + i], 8);
+            off += k;
+        } while (off < to);
+        return;
+    }
+    uint16_t lc_[288], dc_[32], cc_[19];
+    const uint8_t *L = use_dyn ? ll : fl, *D = use_dyn ? dl : fd;
+    canon_codes(L, 288, lc_);
+    canon_codes(D, use_dyn ? 30 : 32, dc_);
+    bw_put(w, (uint32_t)(last ? 1 : 0) | ((use_dyn ? 2u : 1u) << 1), 3);
+    if (use_dyn) {
+        canon_codes(cl, 19, cc_);
+        bw_put(w, (uint32_t)(hlit - 257), 5);
+        bw_put(w, (uint32_t)(hdist - 1), 5);
+        bw_put(w, (uint32_t)(hclen - 4), 4);
+        for (int i = 0; i < hclen; i++) bw_put(w, cl[CL_ORDER[i]], 3);
+        for (int i = 0; i < ns; i++) {
+            int sym = seq[i] & 0xff;
+            bw_put(w, cc_[sym], cl[sym]);
+            if (sym >= 16) bw_put(w, (uint32_t)(seq[i] >> 8), sym == 16 ? 2 : sym == 17 ? 3 : 7);
+        }
+    }
+    for (unsigned i = 0; i < nt; i++) {
+        if (tok[i] & TOK_MATCH) {
+            unsigned len = TOK_LEN(tok[i]), dist = TOK_DIST(tok[i]);
+            int lc = len_code(len), dc = dist_code(dist);
+            bw_put(w, lc_[257 + lc], L[257 + lc]);
+            bw_put(w, len - LBASE[lc], LEXT[lc]);
+            bw_put(w, dc_[dc], D[dc]);
+            bw_put(w, dist - DBASE[dc], DEXT[dc]);
+        } else bw_put(w, lc_[tok[i]], L[tok[i]]);
+    }
+    bw_put(w, lc_[256], L[256]);
+}
+
+static size_t encode_segment_dynamic(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int strategy, int final, int *overflow)
+{
+    bitw w = {out, cap, 0, 0, 0, 0};
+    matcher *m = (matcher *)calloc(1, sizeof *m);
+    uint32_t *tok = (uint32_t *)malloc(TOK_BLOCK * sizeof(uint32_t));
+    unsigned nt = 0;
+    size_t from = 0, base = 0;
+    for (;;) {
+        if (base < n) { nt += chunk_tokens(m, in, n, base, strategy, tok + nt); base += 64; }
+        const int ended = base >= n;
+        if (ended || nt > TOK_BLOCK - 64) {
+            size_t to = ended ? n : base + m->skip;
+            write_block(&w, tok, nt, in, from, to, final && ended);
+            from = to;
+            nt = 0;
+            if (ended) break;
+        }
+    }
+    if (!final) {
+        bw_put(&w, 0, 3); /* empty stored block = sync marker (Z_SYNC_FLUSH) */
+        bw_align(&w);
+        bw_put(&w, 0xffff0000u, 32);
+    } else bw_align(&w);
+    free(tok);
+    free(m);
+    *overflow = w.overflow;
+    return w.len;
+}
+
+/* One byte-aligned deflate segment for in[0..n): level 1 (and Z_FIXED) = one fixed-Huffman block, or stored blocks when
+ * those are smaller; levels 2..9 = dynamic-Huffman blocks; closed by the final-block flag (final) or by a sync
+ * marker (!final).  Returns the size; *overflow is set when cap was too small. */
 static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int level, int strategy, int final, int *overflow)
 {
+    if (level >= 2 && strategy != 4) return encode_segment_dynamic(in, n, out, cap, strategy, final, overflow);
     bitw w = {out, cap, 0, 0, 0, 0};
     size_t ssz = stored_size(n, !final);
     int use_stored = level == 0;
     if (!use_stored) {
-        uint32_t *table = (uint32_t *)calloc(1u << HASH_BITS, sizeof(uint32_t));
+        matcher *m = (matcher *)calloc(1, sizeof *m);
         bw_put(&w, (uint32_t)(final ? 1 : 0) | (1u << 1), 3);
-        size_t skip = 0;
         for (size_t base = 0; base < n; base += 64) {
-            unsigned mlen[64], mdist[64];
-            uint32_t hh[64];
-            for (unsigned l = 0; l < 64; l++) {
-                size_t p = base + l;
-                mlen[l] = 0;
-                hh[l] = 0xffffffffu;
-                if (p + 4 > n) continue;
-                uint32_t v = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
-                uint32_t h = (v * 2654435761u) >> (32 - HASH_BITS);
-                hh[l] = h;
-                uint32_t c = table[h];
-                /* strategy 3 (Z_RLE): the only candidate is the byte before; 2 (Z_HUFFMAN_ONLY): none */
-                if (strategy == 3) c = p > 0 ? (uint32_t)p : 0;
-                if (strategy == 2) c = 0;
-                if (c && p - (c - 1) <= MAX_DIST) {
-                    size_t q = c - 1, lim = n - p < MAX_MATCH ? n - p : MAX_MATCH, k = 0;
-                    while (k < lim && in[q + k] == in[p + k]) k++;
-                    if (k >= MIN_MATCH) { mlen[l] = (unsigned)k; mdist[l] = (unsigned)(p - q); }
-                }
-            }
-            for (unsigned l = 0; l < 64; l++)
-                if (hh[l] != 0xffffffffu && table[hh[l]] < base + l + 1) table[hh[l]] = (uint32_t)(base + l + 1);
-            size_t pos = skip;
-            while (pos < 64 && base + pos < n) {
+            uint32_t tok[64];
+            unsigned nt = chunk_tokens(m, in, n, base, strategy, tok);
+            for (unsigned i = 0; i < nt; i++) {
                 int nb;
-                uint32_t bits;
-                if (mlen[pos] >= MIN_MATCH) { bits = match_bits(mlen[pos], mdist[pos], &nb); pos += mlen[pos]; }
-                else { bits = lit_bits(in[base + pos], &nb); pos += 1; }
+                uint32_t bits = (tok[i] & TOK_MATCH) ? match_bits(TOK_LEN(tok[i]), TOK_DIST(tok[i]), &nb) : lit_bits(tok[i], &nb);
                 bw_put(&w, bits, nb);
             }
-            skip = pos > 64 ? pos - 64 : 0;
         }
-        free(table);
+        free(m);
         bw_put(&w, 0, 7); /* end of block */
         if (!final) {
             bw_put(&w, 0, 3); /* empty stored block = sync marker (Z_SYNC_FLUSH) */
@@ -253,7 +481,8 @@ orc_encode_t orc_deflate_encode(orc_deflate *s, const uint8_t *in, size_t in_len
             s->started = 1;
         }
         int final = op == ORC_OP_FINISH, ovf = 0;
-        size_t bound = stored_size(s->in_len, !final) + 16;
+        /* dynamic levels: a block holds at least TOK_BLOCK - 64 tokens and falls back to stored (at most 6 bytes over) */
+        size_t bound = stored_size(s->in_len, !final) + 6 * (s->in_len / (TOK_BLOCK - 64) + 1) + 16;
         dgrow(&s->out, &s->out_cap, s->out_len + bound);
         s->out_len += encode_segment(s->in, s->in_len, s->out + s->out_len, bound, s->level, s->strategy, final, &ovf);
         if (s->mode == ORC_MODE_GZIP) s->check = orc_crc32(s->check, s->in, s->in_len);
