@@ -825,7 +825,8 @@ def encode_bound(fmt, in_len):
     return lib().chip_encode_bound(int(fmt), int(in_len))
 
 
-def encode_batch(fmt, level, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len=None, status=None, stream=None):
+def encode_batch(fmt, level, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len=None, status=None, stream=None, strategy=0):
+    """chip_encode_batch_ex over device tensors: level 0 stored, 1 fixed Huffman, 2..9 (-1 = 6) dynamic Huffman blocks."""
     import torch
 
     n = in_len.numel()
@@ -837,8 +838,8 @@ def encode_batch(fmt, level, in_buf, in_off, in_len, out_buf, out_off, out_cap, 
     _check_tensors(((in_buf, torch.uint8), (out_buf, torch.uint8), (in_off, torch.int64), (out_off, torch.int64), (in_len, torch.int32),
                     (out_cap, torch.int32), (out_len, torch.int32), (status, torch.int32)))
     with torch.cuda.device(dev):
-        rc = lib().chip_encode_batch(int(fmt), int(level), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off),
-                                     _dp(out_cap), _dp(out_len), _dp(status), _stream_ptr(stream))
+        rc = lib().chip_encode_batch_ex(int(fmt), int(level), int(strategy), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off),
+                                        _dp(out_cap), _dp(out_len), _dp(status), _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"chip_encode_batch failed: {rc}")
     return out_len, status

@@ -117,7 +117,8 @@ int chip_stream_sync(void *stream) { return hipStreamSynchronize((hipStream_t)st
 int chip_trim(void)
 {
     pipes_trim();  // cached host-batch pipelines of the current device (streams, staging and device buffers)
-    return chip::release_inflate_scratch() == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
+    const bool ok = chip::release_inflate_scratch() == hipSuccess;
+    return chip::release_deflate_scratch() == hipSuccess && ok ? CHIP_OK : CHIP_E_LAUNCH;
 }
 
 // ---- batched decode ------------------------------------------------------------------------
@@ -257,6 +258,7 @@ void pipe_destroy(Pipe *p)  // the caller has made p->device current
     if (p->stream) {
         (void)hipStreamSynchronize(p->stream);
         chip::release_inflate_scratch_of(p->stream);
+        chip::release_deflate_scratch_of(p->stream);
         (void)hipStreamDestroy(p->stream);
     }
     chip_device_free(p->d_in);
@@ -1041,7 +1043,8 @@ size_t chip_encode_bound(int format, size_t in_len)
 {
     size_t blocks = in_len ? (in_len + 65534) / 65535 : 1;
     size_t wrap = format == CHIP_FMT_GZIP ? 18 : format == CHIP_FMT_ZLIB ? 6 : 0;
-    return in_len + 5 * blocks + 5 + wrap;
+    // dynamic levels: a block holds at least 16320 tokens and costs at most 6 bytes more than its stored form
+    return in_len + 5 * blocks + 6 * (in_len / 16320 + 1) + 5 + wrap;
 }
 
 int chip_encode_batch(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
@@ -1281,7 +1284,11 @@ void chip_encoder_free(chip_encoder *e)
 {
     if (!e) return;
     DeviceGuard guard(e->device);
-    if (e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream) {
+        (void)hipStreamSynchronize(e->stream);
+        chip::release_deflate_scratch_of(e->stream);  // the stream's token scratch goes with it
+        (void)hipStreamDestroy(e->stream);
+    }
     chip_pinned_free(e->h_in);
     chip_pinned_free(e->h_out);
     chip_pinned_free(e->h_meta);

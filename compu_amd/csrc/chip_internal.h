@@ -59,7 +59,9 @@ struct BatchArgs {
 // launchers (each only enqueues on `stream`)
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);
 hipError_t release_inflate_scratch();  // frees the cached token scratch of the current device (after a device sync)
-void release_inflate_scratch_of(hipStream_t stream);  // the same for one (drained) stream of the current device
+void release_inflate_scratch_of(hipStream_t stream);
+hipError_t release_deflate_scratch();  // the encoder's token scratch (dynamic levels), same rules
+void release_deflate_scratch_of(hipStream_t stream);  // the same for one (drained) stream of the current device
 hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_t stream);
 // Detection-driven router of a mixed batch: appends the index of every gzip / zlib unit to sel_inflate and of every zstd
 // frame to sel_zstd (counts[0], counts[1], zeroed by the call) and answers units that are neither at once.

@@ -15,6 +15,9 @@
 #include "chip_internal.h"
 #include "wave_checksums.h"
 
+#include <map>
+#include <mutex>
+
 namespace chip {
 
 namespace {
@@ -24,8 +27,9 @@ constexpr uint32_t MIN_MATCH = 4, MAX_MATCH = 258, MAX_DIST = 32768;
 constexpr int OUT_DW = 448;  // LDS bit buffer, dwords (a chunk adds at most 62)
 
 struct alignas(16) ELds {
+    static constexpr uint32_t OBUF = OUT_DW + 64;
     uint32_t table[1 << HASH_BITS];
-    uint32_t obuf[OUT_DW + 64];
+    uint32_t obuf[OBUF];
 };
 
 // 4 input bytes at byte offset `off` of the dword-aligned view (little endian)
@@ -50,10 +54,11 @@ __device__ __forceinline__ uint32_t lit_code(uint32_t v, uint32_t &n)
     return rev_bits(0x190 + (v - 144), 9);
 }
 
-__device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint32_t &n)
+// RFC 1951 sec. 3.2.5: length -> code 0..28 (symbol 257 + code), extra-bit count and value
+__device__ __forceinline__ void len_parts(uint32_t len, uint32_t &lc, uint32_t &lext, uint32_t &lxv)
 {
     // length code: 0..7 -> lengths 3..10; then groups of four per extra-bit count; 28 -> 258
-    uint32_t lc, lbase, lext;
+    uint32_t lbase;
     if (len < 11) {
         lc = len - 3;
         lbase = len;
@@ -68,7 +73,13 @@ __device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint
         lc = 4u * lext + 4u + ((x >> lext) & 3u);
         lbase = 3u + ((4u + ((x >> lext) & 3u)) << lext);
     }
-    uint32_t dc, dbase, dext;
+    lxv = len - lbase;
+}
+
+// distance -> code 0..29, extra-bit count and value
+__device__ __forceinline__ void dist_parts(uint32_t dist, uint32_t &dc, uint32_t &dext, uint32_t &dxv)
+{
+    uint32_t dbase;
     if (dist < 5) {
         dc = dist - 1;
         dbase = dist;
@@ -79,6 +90,14 @@ __device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint
         dc = 2u * dext + 2u + ((y >> dext) & 1u);
         dbase = 1u + ((2u + ((y >> dext) & 1u)) << dext);
     }
+    dxv = dist - dbase;
+}
+
+__device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint32_t &n)
+{
+    uint32_t lc, lext, lxv, dc, dext, dxv;
+    len_parts(len, lc, lext, lxv);
+    dist_parts(dist, dc, dext, dxv);
     uint32_t sym = 257 + lc, bits, nb;
     if (sym < 280) {
         bits = rev_bits(sym - 256, 7);
@@ -87,11 +106,11 @@ __device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint
         bits = rev_bits(0xC0 + (sym - 280), 8);
         nb = 8;
     }
-    bits |= (len - lbase) << nb;
+    bits |= lxv << nb;
     nb += lext;
     bits |= rev_bits(dc, 5) << nb;
     nb += 5;
-    bits |= (dist - dbase) << nb;
+    bits |= dxv << nb;
     nb += dext;
     n = nb;
     return bits;
@@ -108,7 +127,8 @@ struct EncArgs {
 
 // LDS bit buffer -> HBM.  `nbits` valid bits in obuf; writes the complete bytes (all of them if
 // `all`), keeps the rest at the front.  Returns bytes written.
-__device__ uint32_t flush_bits(ELds &L, uint8_t *gout, uint32_t cap, uint32_t obytes, uint32_t &nbits, bool all)
+template <class LDS>
+__device__ uint32_t flush_bits(LDS &L, uint8_t *gout, uint32_t cap, uint32_t obytes, uint32_t &nbits, bool all)
 {
     WSYNC();
     const uint32_t lane = lane_id();
@@ -119,16 +139,17 @@ __device__ uint32_t flush_bits(ELds &L, uint8_t *gout, uint32_t cap, uint32_t ob
     WSYNC();
     // keep the partial dword, clear the rest
     uint32_t keep_w = nbytes >> 2;
-    uint32_t carry = (!all && keep_w < (uint32_t)(OUT_DW + 64)) ? L.obuf[keep_w] : 0u;
+    uint32_t carry = (!all && keep_w < LDS::OBUF) ? L.obuf[keep_w] : 0u;
     WSYNC();
-    for (uint32_t j = lane; j < (uint32_t)(OUT_DW + 64); j += 64) L.obuf[j] = j == 0 ? carry : 0u;
+    for (uint32_t j = lane; j < LDS::OBUF; j += 64) L.obuf[j] = j == 0 ? carry : 0u;
     WSYNC();
     nbits = all ? 0u : nbits - nbytes * 8u;
     return nbytes;
 }
 
 // append `n` bits (uniform value) to the bit buffer
-__device__ __forceinline__ void put_uniform(ELds &L, uint32_t &nbits, uint32_t bits, uint32_t n)
+template <class LDS>
+__device__ __forceinline__ void put_uniform(LDS &L, uint32_t &nbits, uint32_t bits, uint32_t n)
 {
     if (lane_id() == 0 && n) {
         uint32_t w = nbits >> 5, sh = nbits & 31u;
@@ -144,11 +165,232 @@ __device__ __forceinline__ uint32_t stored_size(uint32_t n, bool sync)
     return n + 5u * blocks + (sync ? 5u : 0u);
 }
 
-__global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
+// ---- dynamic Huffman blocks (levels 2..9): oracle/oracle_deflate.c write_block() ------------------------------------
+constexpr uint32_t TOK_BLOCK = 16384;  // tokens per block (zlib's lit_bufsize at memLevel 8); a block closes once a
+                                       // further chunk (64 tokens) might not fit
+constexpr uint32_t TOK_MATCH = 0x80000000u;
+__device__ __constant__ static const uint8_t CL_ORDER[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 0};
+
+struct alignas(16) DLds {
+    static constexpr uint32_t OBUF = OUT_DW + 128;  // a group of 64 tokens adds at most 96 dwords
+    uint32_t table[1 << HASH_BITS];
+    uint32_t obuf[OBUF];
+    uint32_t lfreq[288], dfreq[32], cfreq[20];
+    union {
+        struct {
+            uint32_t key[288];     // (frequency << 9 | symbol) of every symbol, unsorted: read by all lanes to rank their own
+            uint32_t w[576];       // leaves (sorted) then internal nodes: weight, later depth
+            uint16_t parent[576];
+            uint16_t sym[288];     // symbol of sorted leaf i
+        } tree;
+        struct {
+            uint32_t lcode[288], dcode[32], ccode[20];  // bit-reversed code | length << 16
+        } code;
+    };
+    uint16_t seq[320];  // code-length sequence: symbol | extra << 8
+    uint8_t ll[288], dl[32], cl[20];
+};
+static_assert(sizeof(DLds) <= 27304, "six waves per CU");
+
+// Code lengths of freq[0..n) (n <= 288) limited to maxbits into len[0..n): Huffman over (frequency, symbol)-sorted
+// leaves, two-queue merge with ties to the leaf; too deep -> all frequencies halved (rounding up) and rebuilt.
+// Sorting is a rank count (all lanes), the merge runs on lane 0, depths come from pointer jumping (all lanes).
+__device__ __forceinline__ void build_lengths(DLds &L, const uint32_t *freq, uint32_t n, uint32_t maxbits, uint8_t *len)
 {
-    __shared__ ELds L;
-    const uint32_t u = blockIdx.x;
-    if (u >= a.b.n) return;
+    const uint32_t lane = lane_id();
+    uint32_t f[5], m = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < 5; j++) {
+        const uint32_t s = lane + 64u * j;
+        f[j] = s < n ? freq[s] : 0u;
+        m += (uint32_t)__popcll(__ballot(f[j] != 0));
+        if (s < n) len[s] = 0;
+    }
+    if (m == 0) return;
+    if (m == 1) {
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++)
+            if (f[j]) len[lane + 64u * j] = 1;
+        return;
+    }
+    const uint32_t root = 2u * m - 2u;
+    for (;;) {
+        uint32_t key[5], rank[5];
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++) {
+            const uint32_t s = lane + 64u * j;
+            key[j] = f[j] ? (f[j] << 9) | s : 0xffffffffu;
+            rank[j] = 0;
+            if (s < n) L.tree.key[s] = key[j];
+        }
+        WSYNC();
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t k = L.tree.key[i];  // the same address in all lanes
+#pragma unroll
+            for (uint32_t j = 0; j < 5; j++) rank[j] += k < key[j] ? 1u : 0u;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++)
+            if (f[j]) {
+                L.tree.w[rank[j]] = f[j];
+                L.tree.sym[rank[j]] = (uint16_t)(lane + 64u * j);
+            }
+        WSYNC();
+        if (lane == 0) {
+            const uint32_t INF = 0xffffffffu;
+            uint32_t li = 0, ii = m, nn = m, wl = L.tree.w[0], wi = INF;
+            while (nn <= root) {
+                uint32_t sum = 0;
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    if (wl <= wi) {
+                        sum += wl;
+                        L.tree.parent[li] = (uint16_t)nn;
+                        li++;
+                        wl = li < m ? L.tree.w[li] : INF;
+                    } else {
+                        sum += wi;
+                        L.tree.parent[ii] = (uint16_t)nn;
+                        ii++;
+                        wi = ii < nn ? L.tree.w[ii] : INF;
+                    }
+                }
+                L.tree.w[nn] = sum;
+                if (ii == nn) wi = sum;  // the internal queue was empty: the new node is its front
+                nn++;
+            }
+            L.tree.parent[root] = (uint16_t)root;
+        }
+        WSYNC();
+        // depth by pointer jumping: after round r a node knows min(depth, 2^r) and its ancestor that far up
+        uint32_t d[9], pp[9];
+#pragma unroll
+        for (uint32_t j = 0; j < 9; j++) {
+            const uint32_t i = lane + 64u * j;
+            pp[j] = i <= root ? L.tree.parent[i] : root;
+            d[j] = i < root ? 1u : 0u;
+        }
+        WSYNC();
+        bool open = true;
+        for (uint32_t r = 0; r < 5 && open; r++) {
+#pragma unroll
+            for (uint32_t j = 0; j < 9; j++) {
+                const uint32_t i = lane + 64u * j;
+                if (i <= root) {
+                    L.tree.w[i] = d[j];
+                    L.tree.parent[i] = (uint16_t)pp[j];
+                }
+            }
+            WSYNC();
+            bool mine_open = false;
+#pragma unroll
+            for (uint32_t j = 0; j < 9; j++) {
+                const uint32_t i = lane + 64u * j;
+                if (i <= root) {
+                    d[j] += L.tree.w[pp[j]];
+                    pp[j] = L.tree.parent[pp[j]];
+                    mine_open |= pp[j] != root;
+                }
+            }
+            WSYNC();
+            open = __ballot(mine_open) != 0;
+        }
+        uint32_t deepest = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++) {  // leaves are the first m nodes
+            const uint32_t i = lane + 64u * j;
+            if (i < m && d[j] > deepest) deepest = d[j];
+        }
+        const bool too_deep = open || __ballot(deepest > maxbits) != 0;
+        if (!too_deep) {
+#pragma unroll
+            for (uint32_t j = 0; j < 5; j++) {
+                const uint32_t i = lane + 64u * j;
+                if (i < m) len[L.tree.sym[i]] = (uint8_t)d[j];
+            }
+            WSYNC();
+            return;
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++) f[j] = f[j] ? (f[j] + 1u) >> 1 : 0u;
+    }
+}
+
+// canonical codes (RFC 1951 sec. 3.2.2) of len[0..n) into code[0..n): bit-reversed code | length << 16
+__device__ __forceinline__ void canon_codes(const uint8_t *len, uint32_t n, uint32_t *code)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    uint32_t l[5], c[5];
+#pragma unroll
+    for (uint32_t j = 0; j < 5; j++) {
+        const uint32_t s = lane + 64u * j;
+        l[j] = s < n ? len[s] : 0u;
+        c[j] = 0;
+    }
+    uint32_t base = 0;
+    for (uint32_t b = 1; b <= 15; b++) {
+        uint32_t running = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 5; j++) {
+            const uint64_t mm = __ballot(l[j] == b);
+            if (l[j] == b) c[j] = base + running + (uint32_t)__popcll(mm & lt);
+            running += (uint32_t)__popcll(mm);
+        }
+        base = (base + running) << 1;
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 5; j++) {
+        const uint32_t s = lane + 64u * j;
+        if (s < n) code[s] = l[j] ? (__brev(c[j]) >> (32u - l[j])) | (l[j] << 16) : 0u;
+    }
+}
+
+// one value of nb <= 48 bits per lane (nb = 0: none), appended in lane order
+__device__ __forceinline__ void put_lanes(DLds &L, uint32_t &nbits, uint64_t bits, uint32_t nb)
+{
+    const uint32_t incl = wave_incl_scan(nb);
+    if (nb) {
+        const uint32_t at = nbits + incl - nb, w = at >> 5, sh = at & 31u;
+        const uint64_t lo = bits << sh;
+        atomicOr(&L.obuf[w], (uint32_t)lo);
+        if (sh + nb > 32) atomicOr(&L.obuf[w + 1], (uint32_t)(lo >> 32));
+        if (sh + nb > 64) atomicOr(&L.obuf[w + 2], (uint32_t)(bits >> (64u - sh)));
+    }
+    nbits += rdlane(incl, 63);
+}
+
+// bits of the stored form of `len` bytes when the stream stands at bit `at` (mod 8)
+__device__ __forceinline__ uint32_t stored_bits(uint32_t at, uint32_t len)
+{
+    uint32_t p = at & 7u, off = 0;
+    const uint32_t p0 = p;
+    do {
+        const uint32_t k = len - off < 65535u ? len - off : 65535u;
+        p = ((p + 3u + 7u) & ~7u) + 32u + 8u * k;
+        off += k;
+    } while (off < len);
+    return p - p0;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return rdlane(wave_incl_scan(v), 63); }
+
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// One unit (one wave).  DYN = false: level 0/1 and Z_FIXED, one fixed-Huffman block or stored blocks (LDS = ELds).
+// DYN = true: levels 2..9, the chunks' tokens go to tokbuf (TOK_BLOCK words of HBM scratch of this wave) and every
+// TOK_BLOCK-64.. tokens a block is written with the cheapest of dynamic / fixed / stored (LDS = DLds).
+template <bool DYN, class LDS>
+__device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, LDS &L, uint32_t *tokbuf)
+{
     const uint32_t lane = lane_id();
     const uint8_t *gin = a.b.in_base + a.b.in_off[u];
     const uint32_t n = a.b.in_len[u];
@@ -164,7 +406,12 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     const uint32_t total_dw = (mis + n + 3u) >> 2;
 
     for (uint32_t j = lane; j < (1u << HASH_BITS); j += 64) L.table[j] = 0;
-    for (uint32_t j = lane; j < (uint32_t)(OUT_DW + 64); j += 64) L.obuf[j] = 0;
+    for (uint32_t j = lane; j < LDS::OBUF; j += 64) L.obuf[j] = 0;
+    if constexpr (DYN) {
+        for (uint32_t j = lane; j < 288; j += 64) L.lfreq[j] = 0;
+        if (lane < 32) L.dfreq[lane] = 0;
+        if (lane < 20) L.cfreq[lane] = 0;
+    }
     WSYNC();
 
     uint32_t obytes = 0, nbits = 0;
@@ -186,8 +433,9 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     uint32_t body_bytes = 0;
 
     if (!use_stored) {
-        put_uniform(L, nbits, (final ? 1u : 0u) | (1u << 1), 3);
+        if constexpr (!DYN) put_uniform(L, nbits, (final ? 1u : 0u) | (1u << 1), 3);
         uint32_t skip = 0;
+        uint32_t ntok = 0, from = 0, xb_lane = 0, nm_lane = 0;  // DYN: the open block
         // Two chunks are in flight: while chunk c is measured, chosen and emitted, chunk c+1 has already done its
         // table lookups and updates (they depend on hashes and positions only, never on what matched) and its
         // candidate bytes are on their way from memory.  Every lane issues the same eleven loads per chunk (lanes
@@ -239,7 +487,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
         };
         Cand cur;
         lookup(cur, 0);
-        for (uint32_t base = 0; base < n; base += 64) {
+        for (uint32_t base = 0; base < n || (DYN && base == 0); base += 64) {
             Cand nxt;
             lookup(nxt, base + 64);  // past the end this is an empty chunk: same loads, nothing looked up
             const uint32_t p = base + lane;
@@ -296,19 +544,220 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
             }
             skip = pos > 64 ? pos - 64 : 0;
             const bool mine = (sel >> lane) & 1ull;
-            uint32_t nb = 0, bits = 0;
-            if (mine) bits = mlen >= MIN_MATCH ? match_code(mlen, mdist, nb) : lit_code(v & 0xffu, nb);
-            const uint32_t incl = wave_incl_scan(nb);
-            if (mine) {
-                uint32_t at = nbits + incl - nb, w = at >> 5, sh = at & 31u;
-                atomicOr(&L.obuf[w], bits << sh);
-                if (sh && (nb + sh > 32)) atomicOr(&L.obuf[w + 1], bits >> (32 - sh));
+            if constexpr (!DYN) {
+                uint32_t nb = 0, bits = 0;
+                if (mine) bits = mlen >= MIN_MATCH ? match_code(mlen, mdist, nb) : lit_code(v & 0xffu, nb);
+                const uint32_t incl = wave_incl_scan(nb);
+                if (mine) {
+                    uint32_t at = nbits + incl - nb, w = at >> 5, sh = at & 31u;
+                    atomicOr(&L.obuf[w], bits << sh);
+                    if (sh && (nb + sh > 32)) atomicOr(&L.obuf[w + 1], bits >> (32 - sh));
+                }
+                nbits += rdlane(incl, 63);
+                if (nbits > (uint32_t)(OUT_DW - 64) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
+            } else {
+                // tokens to the scratch in order, symbol counts to LDS
+                if (mine) {
+                    uint32_t t = v & 0xffu;
+                    if (mlen >= MIN_MATCH) {
+                        uint32_t lc, lext, lxv, dc, dext, dxv;
+                        len_parts(mlen, lc, lext, lxv);
+                        dist_parts(mdist, dc, dext, dxv);
+                        t = TOK_MATCH | ((mdist - 1u) << 9) | (mlen - 3u);
+                        atomicAdd(&L.lfreq[257u + lc], 1u);
+                        atomicAdd(&L.dfreq[dc], 1u);
+                        xb_lane += lext + dext;
+                        nm_lane += 1;
+                    } else {
+                        atomicAdd(&L.lfreq[t], 1u);
+                    }
+                    tokbuf[ntok + (uint32_t)__popcll(sel & lanemask_lt())] = t;
+                }
+                ntok += (uint32_t)__popcll(sel);
+                const bool ended = base + 64 >= n;
+                if (ended || ntok > TOK_BLOCK - 64) {
+                    const uint32_t to = ended ? n : base + 64 + skip;
+                    const bool lastb = final && ended;
+                    const uint32_t xbits = wave_sum(xb_lane), nmatch = wave_sum(nm_lane);
+                    if (lane == 0) L.lfreq[256] += 1;
+                    WSYNC();
+                    build_lengths(L, L.lfreq, 286, 15, L.ll);
+                    build_lengths(L, L.dfreq, 30, 15, L.dl);
+                    if (lane == 0) {
+                        L.ll[286] = L.ll[287] = 0;
+                        L.dl[30] = L.dl[31] = 0;
+                        if (!nmatch) L.dl[0] = 1;  // one distance code is always described
+                    }
+                    WSYNC();
+                    uint32_t hl = 257, hd = 1;
+#pragma unroll
+                    for (uint32_t j = 0; j < 5; j++) {
+                        const uint32_t sy = lane + 64u * j;
+                        if (sy < 286 && L.ll[sy] && sy + 1 > hl) hl = sy + 1;
+                    }
+                    if (lane < 30 && L.dl[lane]) hd = lane + 1;
+                    const uint32_t hlit = wave_max(hl), hdist = wave_max(hd);
+                    // code-length sequence with greedy runs (lane 0)
+                    uint32_t ns = 0, cl_extra = 0;
+                    if (lane == 0) {
+                        const uint32_t na = hlit + hdist;
+                        uint32_t i = 0;
+                        uint32_t nxt_v = L.ll[0];
+                        while (i < na) {
+                            const uint32_t val = nxt_v;
+                            uint32_t run = 1;
+                            for (;;) {
+                                const uint32_t k = i + run;
+                                if (k >= na) break;
+                                nxt_v = k < hlit ? L.ll[k] : L.dl[k - hlit];
+                                if (nxt_v != val) break;
+                                run++;
+                            }
+                            i += run;
+                            if (val == 0) {
+                                while (run >= 11) {
+                                    const uint32_t r = run < 138 ? run : 138;
+                                    L.seq[ns++] = (uint16_t)(18u | ((r - 11u) << 8));
+                                    L.cfreq[18] += 1;
+                                    cl_extra += 7;
+                                    run -= r;
+                                }
+                                if (run >= 3) {
+                                    L.seq[ns++] = (uint16_t)(17u | ((run - 3u) << 8));
+                                    L.cfreq[17] += 1;
+                                    cl_extra += 3;
+                                    run = 0;
+                                }
+                                L.cfreq[0] += run;
+                                while (run-- > 0) L.seq[ns++] = 0;
+                            } else {
+                                L.seq[ns++] = (uint16_t)val;
+                                L.cfreq[val] += 1;
+                                run--;
+                                while (run >= 3) {
+                                    const uint32_t r = run < 6 ? run : 6;
+                                    L.seq[ns++] = (uint16_t)(16u | ((r - 3u) << 8));
+                                    L.cfreq[16] += 1;
+                                    cl_extra += 2;
+                                    run -= r;
+                                }
+                                L.cfreq[val] += run;
+                                while (run-- > 0) L.seq[ns++] = (uint16_t)val;
+                            }
+                        }
+                    }
+                    ns = rdfirst(ns);
+                    cl_extra = rdfirst(cl_extra);
+                    WSYNC();
+                    build_lengths(L, L.cfreq, 19, 7, L.cl);
+                    uint32_t hc = 4;
+                    if (lane < 19 && L.cl[CL_ORDER[lane < 19 ? lane : 19]]) hc = lane + 1 > 4 ? lane + 1 : 4;
+                    const uint32_t hclen = wave_max(hc);
+                    // costs in bits
+                    uint32_t dynp = 0, fixp = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 5; j++) {
+                        const uint32_t sy = lane + 64u * j;
+                        if (sy < 286) {
+                            const uint32_t fr = L.lfreq[sy];
+                            dynp += fr * L.ll[sy];
+                            fixp += fr * (sy < 144 ? 8u : sy < 256 ? 9u : sy < 280 ? 7u : 8u);
+                        }
+                    }
+                    if (lane < 30) {
+                        const uint32_t fr = L.dfreq[lane];
+                        dynp += fr * L.dl[lane];
+                        fixp += fr * 5u;
+                    }
+                    if (lane < 19) dynp += L.cfreq[lane] * L.cl[lane];
+                    const uint32_t dyn = wave_sum(dynp) + 3u + 14u + 3u * hclen + cl_extra + xbits, fix = wave_sum(fixp) + 3u + xbits;
+                    const bool use_dyn = dyn < fix;
+                    const uint32_t huff = use_dyn ? dyn : fix;
+                    WSYNC();
+                    if (stored_bits(nbits, to - from) < huff) {
+                        uint32_t off = from;
+                        do {
+                            const uint32_t k = to - off < 65535u ? to - off : 65535u;
+                            put_uniform(L, nbits, (lastb && off + k == to) ? 1u : 0u, 3);
+                            nbits = (nbits + 7u) & ~7u;
+                            put_uniform(L, nbits, k | ((~k & 0xffffu) << 16), 32);
+                            obytes += flush_bits(L, gout, cap, obytes, nbits, true);
+                            for (uint32_t j = lane; j < k; j += 64)
+                                if (obytes + j < cap) gout[obytes + j] = gin[off + j];
+                            obytes += k;
+                            off += k;
+                        } while (off < to);
+                    } else {
+                        if (!use_dyn) {
+                            for (uint32_t j = lane; j < 288; j += 64) L.ll[j] = j < 144 ? 8 : j < 256 ? 9 : j < 280 ? 7 : 8;
+                            if (lane < 32) L.dl[lane] = lane < 30 ? 5 : 0;
+                            WSYNC();
+                        }
+                        canon_codes(L.ll, 288, L.code.lcode);
+                        canon_codes(L.dl, 30, L.code.dcode);
+                        if (use_dyn) canon_codes(L.cl, 19, L.code.ccode);
+                        WSYNC();
+                        put_uniform(L, nbits, (lastb ? 1u : 0u) | ((use_dyn ? 2u : 1u) << 1), 3);
+                        if (use_dyn) {
+                            put_uniform(L, nbits, (hlit - 257u) | ((hdist - 1u) << 5) | ((hclen - 4u) << 10), 14);
+                            put_lanes(L, nbits, lane < hclen ? L.cl[CL_ORDER[lane < 19 ? lane : 19]] : 0u, lane < hclen ? 3u : 0u);
+                            for (uint32_t g = 0; g < ns; g += 64) {
+                                uint32_t nb = 0;
+                                uint64_t bits = 0;
+                                if (g + lane < ns) {
+                                    const uint32_t e = L.seq[g + lane], sy = e & 0xffu, ce = L.code.ccode[sy];
+                                    nb = ce >> 16;
+                                    bits = (ce & 0xffffu) | ((uint64_t)(e >> 8) << nb);
+                                    nb += sy == 16 ? 2u : sy == 17 ? 3u : sy == 18 ? 7u : 0u;
+                                }
+                                put_lanes(L, nbits, bits, nb);
+                                if (nbits > (DLds::OBUF - 104u) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
+                            }
+                        }
+                        for (uint32_t g = 0; g < ntok; g += 64) {
+                            uint32_t nb = 0;
+                            uint64_t bits = 0;
+                            if (g + lane < ntok) {
+                                const uint32_t t = tokbuf[g + lane];
+                                if (t & TOK_MATCH) {
+                                    uint32_t lc, lext, lxv, dc, dext, dxv;
+                                    len_parts((t & 0xffu) + 3u, lc, lext, lxv);
+                                    dist_parts(((t >> 9) & 0x7fffu) + 1u, dc, dext, dxv);
+                                    const uint32_t le = L.code.lcode[257u + lc], de = L.code.dcode[dc];
+                                    bits = le & 0xffffu;
+                                    nb = le >> 16;
+                                    bits |= (uint64_t)lxv << nb;
+                                    nb += lext;
+                                    bits |= (uint64_t)(de & 0xffffu) << nb;
+                                    nb += de >> 16;
+                                    bits |= (uint64_t)dxv << nb;
+                                    nb += dext;
+                                } else {
+                                    const uint32_t le = L.code.lcode[t];
+                                    bits = le & 0xffffu;
+                                    nb = le >> 16;
+                                }
+                            }
+                            put_lanes(L, nbits, bits, nb);
+                            if (nbits > (DLds::OBUF - 104u) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
+                        }
+                        const uint32_t eob = L.code.lcode[256];
+                        put_uniform(L, nbits, eob & 0xffffu, eob >> 16);
+                    }
+                    // the next block starts empty
+                    WSYNC();
+                    for (uint32_t j = lane; j < 288; j += 64) L.lfreq[j] = 0;
+                    if (lane < 32) L.dfreq[lane] = 0;
+                    if (lane < 20) L.cfreq[lane] = 0;
+                    WSYNC();
+                    ntok = 0;
+                    from = to;
+                    xb_lane = nm_lane = 0;
+                }
             }
-            nbits += rdlane(incl, 63);
-            if (nbits > (uint32_t)(OUT_DW - 64) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
             cur = nxt;
         }
-        put_uniform(L, nbits, 0, 7);  // end of block
+        if constexpr (!DYN) put_uniform(L, nbits, 0, 7);  // end of block
         if (!final) {
             put_uniform(L, nbits, 0, 3);  // empty stored block = sync marker (Z_SYNC_FLUSH)
             nbits = (nbits + 7u) & ~7u;
@@ -316,7 +765,7 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
         } else nbits = (nbits + 7u) & ~7u;
         obytes += flush_bits(L, gout, cap, obytes, nbits, true);
         body_bytes = obytes - hdr_bytes;
-        if (ssz < body_bytes) use_stored = true;
+        if (!DYN && ssz < body_bytes) use_stored = true;
     }
     if (use_stored) {
         // rewrite the body as stored blocks (RFC 1951 sec. 3.2.4); the header bytes are already in place
@@ -367,7 +816,102 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
     }
 }
 
+__global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
+{
+    __shared__ ELds L;
+    if (blockIdx.x >= a.b.n) return;
+    encode_unit<false>(a, blockIdx.x, L, nullptr);
+}
+
+// Persistent grid (the token scratch is per resident wave): each wave takes the next unit from *next_unit.
+__global__ __launch_bounds__(64) void deflate_dyn_kernel(EncArgs a, uint32_t *scratch, uint32_t *next_unit)
+{
+    __shared__ DLds L;
+    uint32_t *tokbuf = scratch + (size_t)blockIdx.x * TOK_BLOCK;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane_id() == 0) i = atomicAdd(next_unit, 1u);
+        i = rdfirst(i);
+        if (i >= a.b.n) break;
+        encode_unit<true>(a, i, L, tokbuf);
+        WSYNC();  // the next unit reuses the LDS
+    }
+}
+
+// Token scratch and the unit counter of the dynamic-level launches, cached per (device, stream) like the
+// inflate kernel's (inflate.hip slot_for): sized for min(n, resident waves) waves.
+struct EncSlot {
+    uint32_t *scratch = nullptr;
+    uint32_t *counter = nullptr;
+    int blocks = 0;
+};
+std::mutex g_enc_mu;
+std::map<std::pair<int, hipStream_t>, EncSlot> g_enc_slots;
+
+hipError_t enc_slot_for(hipStream_t stream, uint32_t n, EncSlot &out)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_enc_mu);
+    EncSlot &sl = g_enc_slots[{dev, stream}];
+    static int max_blocks[64] = {0};
+    const int di = dev < 64 ? dev : 63;
+    if (!max_blocks[di]) {
+        int per_cu = 0, cus = 0;
+        if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, deflate_dyn_kernel, 64, 0)) != hipSuccess) return e;
+        if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+        if (per_cu < 1) per_cu = 1;
+        max_blocks[di] = per_cu * cus;
+    }
+    const int want = n < (uint32_t)max_blocks[di] ? (int)n : max_blocks[di];
+    if (sl.blocks < want) {
+        if (sl.scratch && (e = hipStreamSynchronize(stream)) != hipSuccess) return e;  // launches on the stream still use it
+        (void)hipFree(sl.scratch);
+        sl.scratch = nullptr;
+        sl.blocks = 0;
+        const int blocks = want <= 1 ? 1 : (want + want / 4 < max_blocks[di] ? want + want / 4 : max_blocks[di]);
+        uint32_t *p = nullptr;
+        if ((e = hipMalloc((void **)&p, (size_t)blocks * TOK_BLOCK * 4 + 256)) != hipSuccess) return e;
+        sl.scratch = p;
+        sl.counter = p + (size_t)blocks * TOK_BLOCK;
+        sl.blocks = blocks;
+    }
+    out = sl;
+    return hipSuccess;
+}
+
 }  // namespace
+
+hipError_t release_deflate_scratch()
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if ((e = hipDeviceSynchronize()) != hipSuccess) return e;
+    std::lock_guard<std::mutex> lk(g_enc_mu);
+    for (auto it = g_enc_slots.begin(); it != g_enc_slots.end();) {
+        if (it->first.first == dev) {
+            (void)hipFree(it->second.scratch);
+            it = g_enc_slots.erase(it);
+        } else {
+            ++it;
+        }
+    }
+    return hipSuccess;
+}
+
+void release_deflate_scratch_of(hipStream_t stream)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_enc_mu);
+    auto it = g_enc_slots.find({dev, stream});
+    if (it != g_enc_slots.end()) {
+        (void)hipFree(it->second.scratch);
+        g_enc_slots.erase(it);
+    }
+}
 
 hipError_t launch_deflate_l1(const BatchArgs &b, int level, uint32_t flags, uint32_t check_seed, uint64_t total_before,
                              uint32_t *check_out, hipStream_t stream)
@@ -380,6 +924,19 @@ hipError_t launch_deflate_l1(const BatchArgs &b, int level, uint32_t flags, uint
     a.check_seed = check_seed;
     a.total_before = total_before;
     a.check_out = check_out;
+    const uint32_t strategy = (flags >> 8) & 7u;
+    if (level >= 2 && strategy != CHIP_STRATEGY_FIXED) {
+        EncSlot sl;
+        hipError_t e = enc_slot_for(stream, b.n, sl);
+        if (e != hipSuccess) return e;
+        // counter reset and kernel must reach the stream back to back even when several host threads launch on it
+        static std::mutex enqueue_mu;
+        std::lock_guard<std::mutex> lk(enqueue_mu);
+        if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
+        const uint32_t blocks = b.n < (uint32_t)sl.blocks ? b.n : (uint32_t)sl.blocks;
+        hipLaunchKernelGGL(deflate_dyn_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(deflate_kernel, dim3(b.n), dim3(64), 0, stream, a);
     return hipGetLastError();
 }

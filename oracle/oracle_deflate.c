@@ -192,7 +192,7 @@ static int dist_code(unsigned dist) { int dc = 29; while (DBASE[dc] > dist) dc--
 static void fixed_lengths(uint8_t *ll, uint8_t *dl)
 {
     for (int i = 0; i < 288; i++) ll[i] = i < 144 ? 8 : i < 256 ? 9 : i < 280 ? 7 : 8;
-    for (int i = 0; i < 30; i++) dl[i] = 5;
+    for (int i = 0; i < 32; i++) dl[i] = i < 30 ? 5 : 0;
 }
 
 /* stored form of `len` bytes written at bit position `at` of the stream: bits */
@@ -225,7 +225,7 @@ static void write_block(bitw *w, const uint32_t *tok, unsigned nt, const uint8_t
         } else lfreq[tok[i]]++;
     }
     lfreq[256]++;
-    uint8_t ll[288], dl[32], fl[288], fd[32];
+    uint8_t ll[288], dl[32] = {0}, fl[288], fd[32];
     build_lengths(lfreq, 286, 15, ll);
     ll[286] = ll[287] = 0;
     build_lengths(dfreq, 30, 15, dl);
@@ -284,7 +284,7 @@ static void write_block(bitw *w, const uint32_t *tok, unsigned nt, const uint8_t
     uint16_t lc_[288], dc_[32], cc_[19];
     const uint8_t *L = use_dyn ? ll : fl, *D = use_dyn ? dl : fd;
     canon_codes(L, 288, lc_);
-    canon_codes(D, use_dyn ? 30 : 32, dc_);
+    canon_codes(D, 30, dc_);
     bw_put(w, (uint32_t)(last ? 1 : 0) | ((use_dyn ? 2u : 1u) << 1), 3);
     if (use_dyn) {
         canon_codes(cl, 19, cc_);

@@ -1,6 +1,7 @@
 """The reference's encoder tests (tests/encoder.rs:10-78 test_case, :115-173 test_case_empty_final; zlib-ng
 variants :216-225 gzip, :249-258 zlib, :282-291 deflate, :345-354/:378-387/:411-420 empty-final) replayed
 against the hip encoder + hip decoder, and batch parity of the GPU encoder with the oracle's bytes."""
+import os
 import random
 import zlib
 
@@ -137,7 +138,7 @@ def test_batch_encode_matches_oracle_bytes(gpu, alice):
         for it in range(120):
             n = rnd.choice([0, 1, 3, 4, 5, 63, 64, 65, 100, 1000, 5000, 65535, 65536, 65537, 70000])
             datas.append(_mk(rnd.randrange(5), n, rnd, alice))
-        level = rnd.choice([0, 1, 1])
+        level = {-15: 1, 15: 0, 31: 1}[fmt]
         lens = np.array([len(d) for d in datas], np.int32)
         offs = np.zeros(len(datas), np.int64)
         offs[1:] = np.cumsum(((lens[:-1].astype(np.int64) + 3) & ~3) + rnd.choice([0, 1, 2, 3]))
@@ -167,19 +168,70 @@ def test_batch_encode_matches_oracle_bytes(gpu, alice):
             assert zlib.decompress(comp, fmt) == d
 
 
-def test_level1_ratio_against_zlib(gpu, alice):
-    """Stated bound: on LZ-compressible input the level-1 class encoder stays within 1.5x of zlib level 1."""
+def test_dynamic_levels_match_oracle_bytes(gpu, alice):
+    """Levels 2..9 write dynamic-Huffman blocks (oracle_deflate.c write_block): units of every kind, sizes around the
+    chunk and the 16 384-token block limits (several blocks per unit, stored and fixed blocks among them), all strategies."""
+    import compu_amd as c
+    from oracle import oracle as O
+
+    torch = gpu
+    rnd = random.Random(77)
+    dev = "cuda:0"
+    for fmt, strategy in ((-15, 0), (15, 0), (31, 0), (-15, 2), (15, 3), (31, 1), (-15, 4)):
+        datas = []
+        for it in range(90):
+            n = rnd.choice([0, 1, 3, 4, 5, 63, 64, 65, 100, 1000, 5000, 16319, 16320, 16321, 16384, 40000, 65535, 65536, 70000, 200000])
+            datas.append(_mk(rnd.randrange(5), n, rnd, alice))
+        datas.append((alice * 6)[:900000])
+        datas.append(os.urandom(40000) + alice[:60000] + bytes(50000) + os.urandom(30000))
+        level = rnd.randrange(2, 10)
+        lens = np.array([len(d) for d in datas], np.int32)
+        offs = np.zeros(len(datas), np.int64)
+        offs[1:] = np.cumsum(((lens[:-1].astype(np.int64) + 3) & ~3) + rnd.choice([0, 1, 2, 3]))
+        buf = np.zeros(int(offs[-1] + lens[-1]) + 8, np.uint8)
+        for d, o in zip(datas, offs):
+            buf[o : o + len(d)] = np.frombuffer(d, np.uint8)
+        caps = np.array([c.encode_bound(fmt, len(d)) for d in datas], np.int32)
+        ooff = np.zeros(len(datas), np.int64)
+        ooff[1:] = np.cumsum(caps[:-1].astype(np.int64) + 7)
+        d_out = torch.full((int(ooff[-1] + caps[-1]) + 8,), 0xA5, dtype=torch.uint8, device=dev)
+        out_len, status = c.encode_batch(fmt, level, torch.from_numpy(buf[: (len(buf) // 4) * 4]).to(dev), torch.from_numpy(offs).to(dev),
+                                         torch.from_numpy(lens).to(dev), d_out, torch.from_numpy(ooff).to(dev), torch.from_numpy(caps).to(dev),
+                                         strategy=strategy)
+        torch.cuda.synchronize()
+        h = d_out.cpu().numpy()
+        ol, st = out_len.cpu().numpy(), status.cpu().numpy()
+        kinds = set()
+        for i, d in enumerate(datas):
+            assert st[i] == 2, (fmt, i, st[i])
+            comp = bytes(h[ooff[i] : ooff[i] + ol[i]])
+            assert (h[ooff[i] + caps[i] : ooff[i] + caps[i] + 7] == 0xA5).all()
+            e = O.DeflateEncoder(fmt, level, strategy)
+            ref, ir, orr, est = e.encode(d, int(caps[i]) + 64, O.OP_FINISH)
+            assert est == O.ENC_FINISHED
+            assert comp == ref, (fmt, level, strategy, i, len(d), len(comp), len(ref))
+            assert zlib.decompress(comp, fmt) == d
+            body = comp[{-15: 0, 15: 2, 31: 10}[fmt]:]
+            if body:
+                kinds.add((body[0] >> 1) & 3)
+        assert kinds >= ({1} if strategy == 4 else {0, 1, 2}), kinds  # stored, fixed and dynamic first blocks all occurred
+
+
+def test_ratio_against_zlib(gpu, alice):
+    """Stated bounds on LZ-compressible input: the default level (dynamic Huffman) stays within 1.15x of zlib level 1,
+    level 1 (fixed Huffman, BASELINE.json cfg3) within 1.5x."""
     import compu_amd as c
     from bench_support import synth
 
-    enc = c.encoder_interface.zlib_hip(c.ZlibOptions().mode(c.ZlibMode.Deflate).compression(1))
-    for data in (alice, synth.payloads(4).tobytes()):
-        vec = c.Vec()
-        r = enc.encode_vec_full(data, vec, c.EncodeOp.Finish)
-        assert r.status == c.EncodeStatus.Finished
-        assert zlib.decompress(bytes(vec), -15) == data
-        assert len(vec) <= 1.5 * len(zlib.compress(data, 1))
-        enc.reset()
+    for level, bound in ((-1, 1.15), (1, 1.5)):
+        enc = c.encoder_interface.zlib_hip(c.ZlibOptions().mode(c.ZlibMode.Deflate).compression(level))
+        for data in (alice, synth.payloads(4).tobytes()):
+            vec = c.Vec()
+            r = enc.encode_vec_full(data, vec, c.EncodeOp.Finish)
+            assert r.status == c.EncodeStatus.Finished
+            assert zlib.decompress(bytes(vec), -15) == data
+            assert len(vec) <= bound * len(zlib.compress(data, 1)), (level, len(vec), len(zlib.compress(data, 1)))
+            enc.reset()
 
 
 def test_host_memory_encode_matches_the_oracle(gpu):
