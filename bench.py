@@ -68,7 +68,7 @@ def make_workload(kind, payload, n_units, threads, first_unit=0):
     return packed, offs, lens
 
 
-def run_encode(torch, compu_amd, payload_dev, n_units, steps, warmup, dist):
+def run_encode(torch, compu_amd, payload_dev, n_units, steps, warmup, dist, level=1):
     """BASELINE.json configs[3]: level-1 encode of every unit (raw deflate), verified by inflating it again on the GPU."""
     dev = payload_dev.device
     cap = compu_amd.encode_bound(-15, UNIT)
@@ -82,7 +82,7 @@ def run_encode(torch, compu_amd, payload_dev, n_units, steps, warmup, dist):
     d_status = torch.empty(n_units, dtype=torch.int32, device=dev)
 
     def step():
-        compu_amd.encode_batch(-15, 1, payload_dev, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status)
+        compu_amd.encode_batch(-15, level, payload_dev, d_in_off, d_in_len, d_out, d_out_off, d_out_cap, d_out_len, d_status)
 
     for _ in range(warmup):
         step()
@@ -255,6 +255,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--units", type=int, default=65536, help="units per GPU")
+    ap.add_argument("--encode-level", type=int, default=1, help="--workload encode: 1 = cfg3 (fixed Huffman), 2..9 = dynamic-Huffman blocks")
     ap.add_argument("--workload", default="dynamic", choices=["dynamic", "fixed", "stored", "level1", "mixed", "encode"])
     ap.add_argument("--extra", type=int, default=1, help="also measure the configs[1] variants (stored, fixed)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="units the CPU baseline decodes (about 10-30 s of CPU work in total)")
@@ -316,7 +317,7 @@ def main():
     for kind in kinds:
         steps = args.steps if kind == args.workload else max(3, min(args.steps, 5))
         if kind == "encode":
-            res = run_encode(torch, compu_amd, d_expect, n_units, steps, args.warmup, dist)
+            res = run_encode(torch, compu_amd, d_expect, n_units, steps, args.warmup, dist, level=args.encode_level)
             res["steps"] = steps
             results[kind] = res
             log(f"[bench] encode: kernel {res['kernel_ms_avg']:.3f} ms avg, ratio {res['comp_bytes'] / res['out_bytes']:.3f}, verified={res['verified']}")
@@ -346,6 +347,8 @@ def main():
         "mixed": "cfg4: 64 KiB payload units, gzip (zlib L6) or zstd (L3, checksum) by splitmix64(unit index), routed by Detection",
         "encode": "cfg3: level-1 class DEFLATE encode of 64 KiB units (greedy 32 KiB-window match + fixed Huffman)",
     }
+    if args.workload == "encode" and args.encode_level != 1:
+        names["encode"] = f"level-{args.encode_level} DEFLATE encode of 64 KiB units (greedy 32 KiB-window match + dynamic-Huffman blocks)"
     line = {
         "metric": METRIC,
         "value": round(value, 3),
@@ -371,7 +374,7 @@ def main():
         "verified_bit_exact": bool(all(r["verified"] for r in results.values())),
         "roofline": {
             "bound": "hbm",
-            "kernel": {"mixed": "chip::inflate_kernel + chip::zstd_kernel", "encode": "chip::deflate_kernel"}.get(args.workload, "chip::inflate_kernel"),
+            "kernel": {"mixed": "chip::inflate_kernel + chip::zstd_kernel", "encode": "chip::deflate_kernel" if args.encode_level == 1 else "chip::deflate_dyn_kernel"}.get(args.workload, "chip::inflate_kernel"),
             "achieved": round(ach, 3),
             "peak": HBM_PEAK_GBPS,
             "unit": "GB/s",

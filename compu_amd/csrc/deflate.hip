@@ -41,6 +41,20 @@ __device__ __forceinline__ uint32_t ld32(const uint32_t *g32, uint32_t total_dw,
     return __builtin_amdgcn_alignbit(d1, d0, (off & 3u) * 8u);
 }
 
+// 16 bytes at any address (gfx950 does unaligned global loads)
+struct __attribute__((packed, aligned(1))) U128u {
+    uint32_t x, y, z, w;
+};
+
+// index of the first differing byte of two 16-byte strings, 16 when equal
+__device__ __forceinline__ uint32_t first_diff16(const U128u a, const U128u b)
+{
+    const uint64_t lo = ((uint64_t)(a.y ^ b.y) << 32) | (a.x ^ b.x), hi = ((uint64_t)(a.w ^ b.w) << 32) | (a.z ^ b.z);
+    const uint32_t klo = lo ? ((uint32_t)__ffsll((long long)lo) - 1u) >> 3 : 8u;
+    const uint32_t khi = hi ? (((uint32_t)__ffsll((long long)hi) - 1u) >> 3) + 8u : 16u;
+    return lo ? klo : khi;
+}
+
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
 
 // RFC 1951 sec. 3.2.5 / 3.2.6: one token as LSB-first bits (<= 31)
@@ -442,20 +456,31 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
         // without a candidate compare their own position with itself) so that waiting for chunk c's bytes can leave
         // chunk c+1's in flight.
         struct Cand {
-            uint32_t v, q, qd[5], pd[5];
+            uint32_t v, q;
+            U128u qv, pv;  // 16 bytes at the candidate and at the position (lanes at least 16 bytes before the unit's end)
             bool has;
         };
         const uint32_t last_dw = total_dw ? total_dw - 1u : 0u;
-        uint32_t v_next = lane < n ? ld32(g32, total_dw, mis + lane) : 0u;
+        // 16-byte loads start at most here; a unit under 16 bytes reads the aligned 16 bytes around its start (same page) and ignores them
+        const uint32_t wide_end = n >= 16 ? n - 16u : 0u;
+        const uint8_t *gwide = gin - (n >= 16 ? 0u : (uint32_t)((uintptr_t)gin & 15u));
+        // the 4 bytes at a lane's position are fetched one chunk ahead as two raw aligned dwords and put together when
+        // the chunk is looked up (combining them at once would wait for the load, and for every load before it)
+        uint32_t vd0, vd1;
+        auto fetch_v = [&](uint32_t p) {
+            const uint32_t i = (mis + p) >> 2;  // clamped into the unit
+            vd0 = g32[i < last_dw ? i : last_dw];
+            vd1 = g32[i + 1 < last_dw ? i + 1 : last_dw];
+        };
+        fetch_v(lane);
         auto lookup = [&](Cand &c, uint32_t base) {
             const uint32_t p = base + lane;
             const bool valid4 = p + 4 <= n && base < n;
-            c.v = v_next;
             {
-                const uint32_t off = mis + p + 64u, i = off >> 2;  // the chunk after this one, clamped into the unit
-                const uint32_t d0 = g32[i < last_dw ? i : last_dw], d1 = g32[i + 1 < last_dw ? i + 1 : last_dw];
-                v_next = p + 64 < n ? __builtin_amdgcn_alignbit(i + 1 < total_dw ? d1 : 0u, i < total_dw ? d0 : 0u, (off & 3u) * 8u) : 0u;
+                const uint32_t off = mis + p, i = off >> 2;
+                c.v = p < n ? __builtin_amdgcn_alignbit(i + 1 < total_dw ? vd1 : 0u, i < total_dw ? vd0 : 0u, (off & 3u) * 8u) : 0u;
             }
+            fetch_v(p + 64u);
             uint32_t h = 0;
             c.has = false;
             c.q = p;
@@ -476,12 +501,11 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     c.q = p;
                 }
             }
-            const uint32_t qi = (mis + c.q) >> 2, pi = (mis + p) >> 2;
-#pragma unroll
-            for (uint32_t j = 0; j < 5; j++) {
-                c.qd[j] = g32[qi + j < last_dw ? qi + j : last_dw];
-                c.pd[j] = g32[pi + j < last_dw ? pi + j : last_dw];
-            }
+            // one unaligned 16-byte load per side: a scattered load costs the L1 a tag lookup per lane and instruction
+            // (every lane issues both loads, clamped into the unit, so that waiting for chunk c's bytes leaves chunk
+            // c+1's in flight; lanes in the unit's last 15 bytes do not use them)
+            c.qv = *(const U128u *)(gwide + (c.q < wide_end ? c.q : wide_end));
+            c.pv = *(const U128u *)(gwide + (p < wide_end ? p : wide_end));
             LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the loads stay in flight)
             if (valid4) atomicMax(&L.table[h], p + 1);
         };
@@ -497,25 +521,26 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 const uint32_t q = cur.q;
                 const uint32_t lim = n - p < MAX_MATCH ? n - p : MAX_MATCH;
                 // the first 16 bytes of both sides arrived together: most candidates are decided right here
-                uint32_t k = 16;
-                const uint32_t qs = ((mis + q) & 3u) * 8u, ps = ((mis + p) & 3u) * 8u;
+                uint32_t k = 0;
                 bool diff = false;
-#pragma unroll
-                for (uint32_t j = 0; j < 4; j++) {
-                    const uint32_t x = __builtin_amdgcn_alignbit(cur.qd[j + 1], cur.qd[j], qs) ^ __builtin_amdgcn_alignbit(cur.pd[j + 1], cur.pd[j], ps);
-                    if (!diff && x) {
-                        k = 4u * j + (((uint32_t)__ffs((int)x) - 1u) >> 3);
-                        diff = true;
-                    }
+                if (p + 16 <= n) {
+                    k = first_diff16(cur.qv, cur.pv);
+                    diff = k < 16;
                 }
                 if (!diff) {
                     while (k < lim) {
-                        uint32_t x = ld32(g32, total_dw, mis + q + k) ^ ld32(g32, total_dw, mis + p + k);
-                        if (x) {
-                            k += ((uint32_t)__ffs((int)x) - 1u) >> 3;
-                            break;
+                        if (p + k + 16 <= n) {
+                            const uint32_t d = first_diff16(*(const U128u *)(gin + q + k), *(const U128u *)(gin + p + k));
+                            k += d;
+                            if (d < 16) break;
+                        } else {
+                            uint32_t x = ld32(g32, total_dw, mis + q + k) ^ ld32(g32, total_dw, mis + p + k);
+                            if (x) {
+                                k += ((uint32_t)__ffs((int)x) - 1u) >> 3;
+                                break;
+                            }
+                            k += 4;
                         }
-                        k += 4;
                     }
                 }
                 if (k > lim) k = lim;

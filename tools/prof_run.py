@@ -16,6 +16,19 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 dev = torch.device("cuda:0")
 pay = synth.payloads(n)
+if kind.startswith("encode"):  # encode, encode6, ...: the encoder at that level (default 1) over the raw payload
+    level = int(kind[6:] or 1)
+    cap = (compu_amd.encode_bound(-15, 65536) + 15) & ~15
+    d_in = torch.from_numpy(pay).to(dev)
+    d_out = torch.zeros(n * cap, dtype=torch.uint8, device=dev)
+    ar = torch.arange(n, dtype=torch.int64, device=dev)
+    for _ in range(iters):
+        ol, st = compu_amd.encode_batch(-15, level, d_in, ar * 65536, torch.full((n,), 65536, dtype=torch.int32, device=dev), d_out, ar * cap,
+                                        torch.full((n,), cap, dtype=torch.int32, device=dev))
+    torch.cuda.synchronize()
+    assert (st == 2).all()
+    print("ok", kind, n, "compressed bytes", int(ol.to(torch.int64).sum()))
+    sys.exit(0)
 packed, offs, lens = synth.deflate_units(pay, n, kind=kind)
 d_out = torch.zeros(n * 65536, dtype=torch.uint8, device=dev)
 args = (-15, torch.from_numpy(packed).to(dev), torch.from_numpy(offs.astype(np.int64)).to(dev), torch.from_numpy(lens.astype(np.int32)).to(dev),
