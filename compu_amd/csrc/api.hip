@@ -1043,8 +1043,8 @@ size_t chip_encode_bound(int format, size_t in_len)
 {
     size_t blocks = in_len ? (in_len + 65534) / 65535 : 1;
     size_t wrap = format == CHIP_FMT_GZIP ? 18 : format == CHIP_FMT_ZLIB ? 6 : 0;
-    // dynamic levels: a block holds at least 16320 tokens and costs at most 6 bytes more than its stored form
-    return in_len + 5 * blocks + 6 * (in_len / 16320 + 1) + 5 + wrap;
+    // dynamic levels: a block holds at least 65472 tokens and costs at most 6 bytes more than its stored form
+    return in_len + 5 * blocks + 6 * (in_len / 65472 + 1) + 5 + wrap;
 }
 
 int chip_encode_batch(int format, int level, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,

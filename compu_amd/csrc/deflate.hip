@@ -30,7 +30,9 @@ struct alignas(16) ELds {
     static constexpr uint32_t OBUF = OUT_DW + 64;
     uint32_t table[1 << HASH_BITS];
     uint32_t obuf[OBUF];
+    uint32_t lentab[256];  // per match length 3..258: fixed-Huffman code with the extra bits | bit count << 16
 };
+static_assert(sizeof(ELds) <= 20480, "eight waves per CU");
 
 // 4 input bytes at byte offset `off` of the dword-aligned view (little endian)
 __device__ __forceinline__ uint32_t ld32(const uint32_t *g32, uint32_t total_dw, uint32_t off)
@@ -93,18 +95,13 @@ __device__ __forceinline__ void len_parts(uint32_t len, uint32_t &lc, uint32_t &
 // distance -> code 0..29, extra-bit count and value
 __device__ __forceinline__ void dist_parts(uint32_t dist, uint32_t &dc, uint32_t &dext, uint32_t &dxv)
 {
-    uint32_t dbase;
-    if (dist < 5) {
-        dc = dist - 1;
-        dbase = dist;
-        dext = 0;
-    } else {
-        uint32_t y = dist - 1;                             // 4..32767
-        dext = (31u - (uint32_t)__clz((int)y)) - 1u;       // 1..13
-        dc = 2u * dext + 2u + ((y >> dext) & 1u);
-        dbase = 1u + ((2u + ((y >> dext) & 1u)) << dext);
-    }
-    dxv = dist - dbase;
+    // codes come in pairs per extra-bit count: with h = the top bit of y = dist-1, the code is 2h + the bit below it
+    // (y < 2: the code is y itself, which the same expression gives with the extra-bit count held at 0)
+    const uint32_t y = dist - 1u;                               // 0..32767
+    const uint32_t h = 31u - (uint32_t)__clz((int)(y | 1u));    // 0..14
+    dext = (h > 1u ? h : 1u) - 1u;                              // 0..13
+    dc = 2u * h + ((y >> dext) & 1u);
+    dxv = y & ~(~0u << dext);
 }
 
 __device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint32_t &n)
@@ -148,7 +145,21 @@ __device__ uint32_t flush_bits(LDS &L, uint8_t *gout, uint32_t cap, uint32_t oby
     const uint32_t lane = lane_id();
     uint32_t nbytes = all ? (nbits + 7u) >> 3 : (nbits >> 5) << 2;  // whole dwords unless closing
     const uint8_t *src = (const uint8_t *)L.obuf;
-    for (uint32_t j = lane; j < nbytes; j += 64)
+    // whole dwords (gfx950 stores them at any address), then the last bytes
+    struct __attribute__((packed, aligned(1))) U32u {
+        uint32_t v;
+    };
+    const uint32_t ndw = nbytes >> 2;
+    for (uint32_t j = lane; j < ndw; j += 64) {
+        const uint32_t at = obytes + 4u * j;
+        if (at + 4u <= cap) {
+            ((U32u *)(gout + at))->v = L.obuf[j];
+        } else {
+            for (uint32_t b = 0; b < 4; b++)
+                if (at + b < cap) gout[at + b] = src[4u * j + b];
+        }
+    }
+    for (uint32_t j = 4u * ndw + lane; j < nbytes; j += 64)
         if (obytes + j < cap) gout[obytes + j] = src[j];
     WSYNC();
     // keep the partial dword, clear the rest
@@ -180,13 +191,14 @@ __device__ __forceinline__ uint32_t stored_size(uint32_t n, bool sync)
 }
 
 // ---- dynamic Huffman blocks (levels 2..9): oracle/oracle_deflate.c write_block() ------------------------------------
-constexpr uint32_t TOK_BLOCK = 16384;  // tokens per block (zlib's lit_bufsize at memLevel 8); a block closes once a
+constexpr uint32_t TOK_BLOCK = 65536;  // tokens per block (a 64 KiB unit is one block: the per-block work, three code
+                                       // constructions and a second pass over the tokens, is paid once); a block closes once a
                                        // further chunk (64 tokens) might not fit
 constexpr uint32_t TOK_MATCH = 0x80000000u;
 __device__ __constant__ static const uint8_t CL_ORDER[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 0};
 
 struct alignas(16) DLds {
-    static constexpr uint32_t OBUF = OUT_DW + 128;  // a group of 64 tokens adds at most 96 dwords
+    static constexpr uint32_t OBUF = 416;  // dwords; a group of 64 tokens adds at most 96
     uint32_t table[1 << HASH_BITS];
     uint32_t obuf[OBUF];
     uint32_t lfreq[288], dfreq[32], cfreq[20];
@@ -203,8 +215,9 @@ struct alignas(16) DLds {
     };
     uint16_t seq[320];  // code-length sequence: symbol | extra << 8
     uint8_t ll[288], dl[32], cl[20];
+    uint32_t lentab[256];  // per match length 3..258: length code 0..28 | extra-bit count << 8 | extra-bit value << 16
 };
-static_assert(sizeof(DLds) <= 27304, "six waves per CU");
+static_assert(sizeof(DLds) <= 26624, "six waves per CU (LDS is granted in 1 KB steps: 27 KB would leave five)");
 
 // Code lengths of freq[0..n) (n <= 288) limited to maxbits into len[0..n): Huffman over (frequency, symbol)-sorted
 // leaves, two-queue merge with ties to the leaf; too deep -> all frequencies halved (rounding up) and rebuilt.
@@ -421,6 +434,17 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
 
     for (uint32_t j = lane; j < (1u << HASH_BITS); j += 64) L.table[j] = 0;
     for (uint32_t j = lane; j < LDS::OBUF; j += 64) L.obuf[j] = 0;
+    for (uint32_t j = lane; j < 256; j += 64) {
+        uint32_t lc, lext, lxv;
+        len_parts(j + 3u, lc, lext, lxv);
+        if constexpr (DYN) {
+            L.lentab[j] = lc | (lext << 8) | (lxv << 16);
+        } else {
+            const uint32_t sym = 257u + lc, nb = sym < 280 ? 7u : 8u;
+            const uint32_t code = sym < 280 ? rev_bits(sym - 256, 7) : rev_bits(0xC0 + (sym - 280), 8);
+            L.lentab[j] = code | (lxv << nb) | ((nb + lext) << 16);
+        }
+    }
     if constexpr (DYN) {
         for (uint32_t j = lane; j < 288; j += 64) L.lfreq[j] = 0;
         if (lane < 32) L.dfreq[lane] = 0;
@@ -467,13 +491,13 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
         // the 4 bytes at a lane's position are fetched one chunk ahead as two raw aligned dwords and put together when
         // the chunk is looked up (combining them at once would wait for the load, and for every load before it)
         uint32_t vd0, vd1;
-        auto fetch_v = [&](uint32_t p) {
+        auto fetch_v = [&](uint32_t p) __attribute__((always_inline)) {
             const uint32_t i = (mis + p) >> 2;  // clamped into the unit
             vd0 = g32[i < last_dw ? i : last_dw];
             vd1 = g32[i + 1 < last_dw ? i + 1 : last_dw];
         };
         fetch_v(lane);
-        auto lookup = [&](Cand &c, uint32_t base) {
+        auto lookup = [&](Cand &c, uint32_t base) __attribute__((always_inline)) {
             const uint32_t p = base + lane;
             const bool valid4 = p + 4 <= n && base < n;
             {
@@ -509,10 +533,8 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the loads stay in flight)
             if (valid4) atomicMax(&L.table[h], p + 1);
         };
-        Cand cur;
-        lookup(cur, 0);
-        for (uint32_t base = 0; base < n || (DYN && base == 0); base += 64) {
-            Cand nxt;
+        // one chunk: look the next one up (its loads fly while this one is worked on), measure, choose, emit
+        auto step = [&](Cand &cur, Cand &nxt, const uint32_t base) __attribute__((always_inline)) {
             lookup(nxt, base + 64);  // past the end this is an empty chunk: same loads, nothing looked up
             const uint32_t p = base + lane;
             uint32_t mlen = 0, mdist = 0;
@@ -554,24 +576,37 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             const uint32_t lim64 = n - base < 64 ? n - base : 64;
             const uint64_t limmask = lim64 >= 64 ? ~0ull : ((1ull << lim64) - 1ull);
             const uint64_t cand = __ballot(mlen >= MIN_MATCH) & limmask;
-            uint64_t sel = 0;
+            uint64_t covered = 0;  // positions inside a chosen match (its start excluded)
             uint32_t pos = skip;
             while (pos < lim64) {
-                const uint64_t rest = cand & ~((1ull << pos) - 1ull);
-                if (!rest) {
-                    sel |= limmask & ~((1ull << pos) - 1ull);
-                    pos = lim64;
-                    break;
-                }
-                const uint32_t c = (uint32_t)__ffsll((long long)rest) - 1;
-                sel |= ((c >= 63 ? ~0ull : ((2ull << c) - 1ull))) & ~((1ull << pos) - 1ull);
-                pos = c + rdlane(mlen, c);
+                const uint64_t rest = cand & (~0ull << pos);
+                if (!rest) break;  // literals up to the end of the chunk
+                const uint32_t c = (uint32_t)__builtin_ctzll(rest);
+                const uint32_t len = rdlane(mlen, c);
+                pos = c + len;
+                const uint32_t room = 63u - c, size = len - 1u < room ? len - 1u : room;
+                covered |= ((1ull << size) - 1ull) << ((c + 1u) & 63u);  // `size` ones from bit c+1 (none when c = 63)
             }
+            const uint64_t sel = skip < 64 ? limmask & ~covered & (~0ull << skip) : 0ull;
             skip = pos > 64 ? pos - 64 : 0;
             const bool mine = (sel >> lane) & 1ull;
             if constexpr (!DYN) {
                 uint32_t nb = 0, bits = 0;
-                if (mine) bits = mlen >= MIN_MATCH ? match_code(mlen, mdist, nb) : lit_code(v & 0xffu, nb);
+                if (mine) {
+                    // literal and match both computed, one kept (no divergent branches)
+                    const uint32_t lit = v & 0xffu, lnb = lit < 144 ? 8u : 9u;
+                    const uint32_t lbits = rev_bits(lit < 144 ? 0x30u + lit : 0x100u + lit, 9) >> (9u - lnb);
+                    const uint32_t e = L.lentab[mlen >= MIN_MATCH ? mlen - 3u : 0u];
+                    uint32_t dc, dext, dxv;
+                    dist_parts(mlen >= MIN_MATCH ? mdist : 1u, dc, dext, dxv);
+                    uint32_t mnb = e >> 16, mbits = e & 0xffffu;
+                    mbits |= rev_bits(dc, 5) << mnb;
+                    mnb += 5;
+                    mbits |= dxv << mnb;
+                    mnb += dext;
+                    bits = mlen >= MIN_MATCH ? mbits : lbits;
+                    nb = mlen >= MIN_MATCH ? mnb : lnb;
+                }
                 const uint32_t incl = wave_incl_scan(nb);
                 if (mine) {
                     uint32_t at = nbits + incl - nb, w = at >> 5, sh = at & 31u;
@@ -585,13 +620,13 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 if (mine) {
                     uint32_t t = v & 0xffu;
                     if (mlen >= MIN_MATCH) {
-                        uint32_t lc, lext, lxv, dc, dext, dxv;
-                        len_parts(mlen, lc, lext, lxv);
+                        uint32_t dc, dext, dxv;
+                        const uint32_t e = L.lentab[mlen - 3u];
                         dist_parts(mdist, dc, dext, dxv);
                         t = TOK_MATCH | ((mdist - 1u) << 9) | (mlen - 3u);
-                        atomicAdd(&L.lfreq[257u + lc], 1u);
+                        atomicAdd(&L.lfreq[257u + (e & 0xffu)], 1u);
                         atomicAdd(&L.dfreq[dc], 1u);
-                        xb_lane += lext + dext;
+                        xb_lane += ((e >> 8) & 0xffu) + dext;
                         nm_lane += 1;
                     } else {
                         atomicAdd(&L.lfreq[t], 1u);
@@ -599,8 +634,31 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     tokbuf[ntok + (uint32_t)__popcll(sel & lanemask_lt())] = t;
                 }
                 ntok += (uint32_t)__popcll(sel);
-                const bool ended = base + 64 >= n;
-                if (ended || ntok > TOK_BLOCK - 64) {
+            }
+        };
+        // Two chunks per trip with the candidate registers changing roles, so that no loaded register has to be copied
+        // (a copy would wait for the loads just issued).
+        Cand A, B;
+        lookup(A, 0);
+        for (uint32_t base = 0; base < n || (DYN && base == 0); base += 64) {
+            step(A, B, base);
+            bool ended = false, close = false;
+            if constexpr (DYN) {
+                ended = base + 64 >= n;
+                close = ended || ntok > TOK_BLOCK - 64;
+            }
+            if (!close && base + 64 < n) {
+                base += 64;
+                step(B, A, base);
+                if constexpr (DYN) {
+                    ended = base + 64 >= n;
+                    close = ended || ntok > TOK_BLOCK - 64;
+                }
+            } else {
+                A = B;
+            }
+            if constexpr (DYN) {
+                if (close) {
                     const uint32_t to = ended ? n : base + 64 + skip;
                     const bool lastb = final && ended;
                     const uint32_t xbits = wave_sum(xb_lane), nmatch = wave_sum(nm_lane);
@@ -745,8 +803,8 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                             if (g + lane < ntok) {
                                 const uint32_t t = tokbuf[g + lane];
                                 if (t & TOK_MATCH) {
-                                    uint32_t lc, lext, lxv, dc, dext, dxv;
-                                    len_parts((t & 0xffu) + 3u, lc, lext, lxv);
+                                    uint32_t dc, dext, dxv;
+                                    const uint32_t e = L.lentab[t & 0xffu], lc = e & 0xffu, lext = (e >> 8) & 0xffu, lxv = e >> 16;
                                     dist_parts(((t >> 9) & 0x7fffu) + 1u, dc, dext, dxv);
                                     const uint32_t le = L.code.lcode[257u + lc], de = L.code.dcode[dc];
                                     bits = le & 0xffffu;
@@ -780,7 +838,6 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     xb_lane = nm_lane = 0;
                 }
             }
-            cur = nxt;
         }
         if constexpr (!DYN) put_uniform(L, nbits, 0, 7);  // end of block
         if (!final) {

@@ -133,12 +133,13 @@ static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t bas
 }
 
 /* ---- dynamic Huffman blocks (levels 2..9) ------------------------------------------------------
- * Blocks close after TOK_BLOCK - 64 tokens or more (zlib's lit_bufsize at memLevel 8 is the same 16384).
+ * Blocks close after TOK_BLOCK - 64 tokens or more (65 536: a 64 KiB unit is one block; zlib's lit_bufsize is
+ * 16 384 at memLevel 8, 32 768 at 9).
  * Code lengths: plain Huffman over (frequency, symbol)-sorted leaves with the two-queue method (ties
  * take the leaf); when the deepest leaf exceeds the limit every frequency is halved (rounding up)
  * and the tree rebuilt.  Canonical codes and the code-length header follow RFC 1951 sec. 3.2.2 / 3.2.7
  * with a greedy run-length pass.  Per block the cheapest of dynamic, fixed and stored is written. */
-#define TOK_BLOCK 16384u
+#define TOK_BLOCK 65536u
 static const uint8_t CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
 
 static void build_lengths(const uint32_t *freq_in, int n, int maxbits, uint8_t *len)

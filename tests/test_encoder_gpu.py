@@ -170,7 +170,7 @@ def test_batch_encode_matches_oracle_bytes(gpu, alice):
 
 def test_dynamic_levels_match_oracle_bytes(gpu, alice):
     """Levels 2..9 write dynamic-Huffman blocks (oracle_deflate.c write_block): units of every kind, sizes around the
-    chunk and the 16 384-token block limits (several blocks per unit, stored and fixed blocks among them), all strategies."""
+    chunk and the 65 536-token block limits (several blocks per unit, stored and fixed blocks among them), all strategies."""
     import compu_amd as c
     from oracle import oracle as O
 
@@ -180,7 +180,7 @@ def test_dynamic_levels_match_oracle_bytes(gpu, alice):
     for fmt, strategy in ((-15, 0), (15, 0), (31, 0), (-15, 2), (15, 3), (31, 1), (-15, 4)):
         datas = []
         for it in range(90):
-            n = rnd.choice([0, 1, 3, 4, 5, 63, 64, 65, 100, 1000, 5000, 16319, 16320, 16321, 16384, 40000, 65535, 65536, 70000, 200000])
+            n = rnd.choice([0, 1, 3, 4, 5, 63, 64, 65, 100, 1000, 5000, 16384, 40000, 65471, 65472, 65473, 65535, 65536, 70000, 200000])
             datas.append(_mk(rnd.randrange(5), n, rnd, alice))
         datas.append((alice * 6)[:900000])
         datas.append(os.urandom(40000) + alice[:60000] + bytes(50000) + os.urandom(30000))
