@@ -1,17 +1,18 @@
-// Batched DEFLATE level-1 class encoder for gfx950 (MI355X): one wavefront encodes one unit.
+// Batched DEFLATE encoder for gfx950 (MI355X): one wavefront encodes one unit.
 //
 // Replaces, per unit, what compu reaches through sys::deflate (src/encoder/mod.rs:352) for an encoder
-// built by Interface::zlib_ng(ZlibOptions::new().compression(1)) (src/encoder/zlib_ng.rs:50-87):
-// greedy hash matching in a 32 KiB window and fixed-Huffman emission (the shape of zlib-ng's
-// deflate_quick), gzip / zlib wrappers with CRC-32 / Adler-32 trailers.  compu's own tests pin the
-// encoder by round trip and cross-API determinism only (tests/encoder.rs:10-78); the exact algorithm
-// is stated in oracle/oracle_deflate.c and this kernel reproduces its output byte for byte.
+// built by Interface::zlib_ng(ZlibOptions) (src/encoder/zlib_ng.rs:50-87): greedy hash matching in a
+// 32 KiB window; level 1 writes one fixed-Huffman block (the shape of zlib-ng's deflate_quick; BASELINE
+// configs[3]), levels 2..9 dynamic-Huffman blocks; gzip / zlib wrappers with CRC-32 / Adler-32 trailers.
+// compu's own tests pin the encoder by round trip and cross-API determinism only (tests/encoder.rs:10-78);
+// the exact algorithm is stated in oracle/oracle_deflate.c and these kernels reproduce its output byte for byte.
 //
 // Per 64-position chunk: every lane hashes the 4 bytes at its position, looks the hash table (LDS,
-// state before the chunk) up, measures the common prefix with the candidate (4-byte compares from
+// state before the chunk) up, measures the common prefix with the candidate (16-byte compares from
 // HBM/L2), the table then takes the highest position per slot (ds_max), the greedy token choice is
-// a scalar walk over the 64 match lengths, and the chosen tokens are packed with a wave prefix sum
-// of their bit lengths into an LDS bit buffer that is flushed to HBM.
+// a scalar walk over the chosen matches.  Level 1: the tokens are packed at once with a wave prefix sum
+// of their bit lengths into an LDS bit buffer that is flushed to HBM.  Levels 2..9: the tokens go to HBM
+// scratch and are coded when the block closes (code lengths, header, second pass over the tokens).
 #include "chip_internal.h"
 #include "wave_checksums.h"
 

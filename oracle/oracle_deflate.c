@@ -1,5 +1,5 @@
 /*
- * oracle/oracle_deflate.c -- CPU restatement of the level-1 class DEFLATE encoder behind
+ * oracle/oracle_deflate.c -- CPU restatement of the greedy DEFLATE encoder behind
  * encoder::Interface::zlib_ng(opts) (src/encoder/zlib_ng.rs:50-92, src/encoder/mod.rs:334-370).
  * TEST INFRASTRUCTURE ONLY (see oracle.h).
  *
@@ -14,8 +14,9 @@
  * a 4096-entry hash table of 4-byte hashes as it stood BEFORE the chunk (so candidates are at least
  * one chunk back and the 64 lookups are independent), the match length is the common prefix (4..258
  * bytes, distance <= 32768), then the table takes the highest position per slot.  Tokens are chosen
- * greedily left to right and emitted with the fixed Huffman code (RFC 1951 sec. 3.2.6).  A segment
- * whose fixed-Huffman form is not smaller than stored blocks is emitted stored.  Level 0 = stored.
+ * greedily left to right.  Level 1 (and Z_FIXED): emitted with the fixed Huffman code (RFC 1951
+ * sec. 3.2.6); a segment whose fixed-Huffman form is not smaller than stored blocks is emitted stored.
+ * Levels 2..9: the same tokens in dynamic-Huffman blocks (write_block below).  Level 0 = stored.
  */
 #include "oracle.h"
 
