@@ -1112,15 +1112,18 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         p += (uint32_t)c;
                         left -= (uint32_t)c;
                     } else if (!*t.valid) ZFAIL(ZSTD_E_CORRUPTION);
-                    if (mode != 3 && k != 1) {
-                        // a freshly built LL / ML table also carries, per state, how many extra bits its code reads
-                        // ([14:10]): the serial state chain then needs no second lookup to find the next state's bits
+                    if (mode != 3) {
+                        // A freshly built table is re-coded for the serial state chain below: [4:0] state bits (used as
+                        // they are as v_bfe widths and offsets), [11:5] state bits + extra bits of the code (the sum of
+                        // the three entries' low halves gives the bits a sequence consumes), [17:12] the code,
+                        // [31:23] the baseline of the next state.
                         WSYNC();
                         const uint32_t *xt = k == 0 ? L.lltab : L.mltab;
                         const uint32_t size = 1u << *t.al;
                         for (uint32_t u = lane; u < size; u += 64) {
-                            const uint32_t e = t.e[u];
-                            t.e[u] = e | ((xt[e & 63u] >> 24) << 10);
+                            const uint32_t e = t.e[u], sym = e & 63u, nb = (e >> 6) & 15u, base = e >> 16;
+                            const uint32_t xb = k == 1 ? sym : xt[sym] >> 24;
+                            t.e[u] = nb | ((nb + xb) << 5) | (sym << 12) | (base << 23);
                         }
                     }
                 }
@@ -1129,7 +1132,8 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 if (!bb_init(b, s0, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
                 SeqBits s;
                 sq_init(L, b, s, s0.lo, s0.avail);
-                uint32_t sl = sq_read(L, b, s, L.ll.al), so = sq_read(L, b, s, L.of.al), sm = sq_read(L, b, s, L.ml.al);
+                // the three FSE states, kept as byte offsets into their tables
+                uint32_t al = sq_read(L, b, s, L.ll.al) << 2, ao = sq_read(L, b, s, L.of.al) << 2, am = sq_read(L, b, s, L.ml.al) << 2;
                 s.avail -= (int32_t)s.used;
                 s.used = 0;
                 if (s.avail < 0) ZFAIL(ZSTD_E_CORRUPTION);
@@ -1151,72 +1155,87 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     s.avail -= (int32_t)s.used;
                     s.used = 0;
                     if ((((int32_t)s.lo + s.avail - 64 - 64 * 96) >> 5) < s.win0) sq_fill(L, b, s);
-                    uint32_t my_el = 0, my_eo = 0, my_em = 0;
-                    int32_t my_top = 0;
+                    // States are kept as byte offsets into their tables.  Per sequence: six LDS reads in flight together
+                    // (the 64 bits below the read position and the three entries), one add of the entries gives the bits
+                    // consumed, one 64-bit shift brings the state bits to the bottom, three v_bfe with the entries
+                    // themselves as width / offset operands cut them, and the three state offsets are parked in LDS
+                    // for the lane that finishes the sequence.  The last sequence of a block updates no state.
+                    const uint32_t n_upd = i0 + cn == nseq ? cn - 1u : cn;
+                    const int32_t T0 = (int32_t)s.lo + s.avail, Tmin = (int32_t)s.lo;
+                    int32_t T = T0;
                     __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
                     for (uint32_t j = 0; j < cn; j++) {
-                        // the 64 bits below the read position and the three state entries: six LDS reads in flight together
-                        const int32_t top = (int32_t)s.lo + s.avail;
-                        int32_t wi = ((top - 64) >> 5) - s.win0;
+                        int32_t wi = ((T - 64) >> 5) - s.win0;
                         wi = wi < 0 ? 0 : wi;
                         const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
-                        const uint32_t el = L.ll.e[sl], eo = L.of.e[so], em = L.ml.e[sm];
-                        const uint32_t sh = (uint32_t)(top - 64) & 31u;
-                        uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, sh), wlo = __builtin_amdgcn_alignbit(d1, d0, sh);
-                        const uint32_t xl = (el >> 10) & 31u, xm = (em >> 10) & 31u;
-                        const uint32_t xe = (eo & 63u) + xm + xl;  // offset, match-length and literal-length extras (<= 63 bits)
-                        const bool more = i0 + j + 1 < nseq;  // the last sequence of a block updates no state
-                        const uint32_t nl = (el >> 6) & 15u, nm = (em >> 6) & 15u, no = (eo >> 6) & 15u;
-                        const uint32_t n3 = more ? nl + nm + no : 0u;  // <= 9 + 9 + 8 bits: LL, then ML, then OF
-                        int32_t x = 64 - (int32_t)(xe + n3);  // bit of the 64 at which the state bits start
-                        if (x < 0) {
+                        const uint32_t el = *(const uint32_t *)((const char *)L.ll.e + al), eo = *(const uint32_t *)((const char *)L.of.e + ao),
+                                       em = *(const uint32_t *)((const char *)L.ml.e + am);
+                        L.xpar[3 * j] = al;
+                        L.xpar[3 * j + 1] = ao;
+                        L.xpar[3 * j + 2] = am;
+                        const uint32_t S = el + eo + em;  // [4:0] the three state-bit counts, [11:5] those + the extra bits
+                        uint32_t tot = (S >> 5) & 127u;
+                        if (j >= n_upd) {  // the block's last sequence: extras only
+                            T -= (int32_t)(tot - (S & 31u));
+                            if (T < Tmin) dec_bad = j;
+                            break;
+                        }
+                        uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)T), wlo = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)T);
+                        uint32_t x = 64u - tot;
+                        if (tot > 64u) {
                             // rare: extras and state bits do not fit one 64-bit view; take a second one below the extras
-                            const int32_t q2 = top - (int32_t)xe - 64;
+                            const uint32_t n3 = S & 31u;
+                            const int32_t q2 = T - (int32_t)(tot - n3) - 64;
                             int32_t w2 = (q2 >> 5) - s.win0;
                             w2 = w2 < 0 ? 0 : w2;
                             const uint32_t e0 = L.seqwin[w2], e1 = L.seqwin[w2 + 1], e2 = L.seqwin[w2 + 2];
-                            const uint32_t s2 = (uint32_t)q2 & 31u;
-                            whi = __builtin_amdgcn_alignbit(e2, e1, s2);
-                            wlo = __builtin_amdgcn_alignbit(e1, e0, s2);
-                            x = 64 - (int32_t)n3;
+                            whi = __builtin_amdgcn_alignbit(e2, e1, (uint32_t)q2);
+                            wlo = __builtin_amdgcn_alignbit(e1, e0, (uint32_t)q2);
+                            x = 64u - n3;
                         }
-                        const uint32_t v = x >= 32 ? whi >> (x - 32) : __builtin_amdgcn_alignbit(whi, wlo, (uint32_t)x);
-                        const uint32_t st3 = v & ((1u << n3) - 1u);
-                        if (more) {
-                            sl = (el >> 16) + (st3 >> (nm + no));
-                            sm = (em >> 16) + ((st3 >> no) & ((1u << nm) - 1u));
-                            so = (eo >> 16) + (st3 & ((1u << no) - 1u));
-                        }
-                        s.avail -= (int32_t)(xe + n3);
-                        if (s.avail < 0) {
+                        const uint32_t W = (uint32_t)((((uint64_t)whi << 32) | wlo) >> (x & 63u));  // LL, ML, OF state bits, OF lowest
+                        al = (__builtin_amdgcn_ubfe(el, 23, 9) + __builtin_amdgcn_ubfe(W, eo + em, el)) << 2;
+                        am = (__builtin_amdgcn_ubfe(em, 23, 9) + __builtin_amdgcn_ubfe(W, eo, em)) << 2;
+                        ao = (__builtin_amdgcn_ubfe(eo, 23, 9) + __builtin_amdgcn_ubfe(W, 0, eo)) << 2;
+                        T -= (int32_t)tot;
+                        if (T < Tmin) {
                             dec_bad = j;
                             break;
                         }
-                        if (lane == j) {
-                            my_el = el;
-                            my_eo = eo;
-                            my_em = em;
-                            my_top = top;
-                        }
                     }
                     __builtin_amdgcn_s_setprio(0);
-                    // ---- parallel part: lane j cuts sequence j's extra bits from the window and forms the values
+                    s.avail = T - (int32_t)s.lo;
+                    // ---- parallel part: lane j reads sequence j's entries again, finds its bit position by a prefix sum of
+                    // the bits consumed, cuts the extra bits from the window and forms the values
                     uint32_t ov = 4;
-                    if (lane < cn && lane < dec_bad) {
-                        const uint32_t oc = my_eo & 63u, mc = my_em & 63u, lc = my_el & 63u;
-                        const uint32_t xl = (my_el >> 10) & 31u, xm = (my_em >> 10) & 31u;
-                        const int32_t q = my_top - 64;
-                        int32_t wi = (q >> 5) - s.win0;
-                        wi = wi < 0 ? 0 : (wi > 253 ? 253 : wi);
-                        const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
-                        const uint32_t sh = (uint32_t)q & 31u;
-                        const uint64_t w64 = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
-                        const uint32_t obits = oc ? (uint32_t)(w64 >> (64u - oc)) : 0u;
-                        const uint32_t mlx = xm ? (uint32_t)((w64 << oc) >> (64u - xm)) : 0u;
-                        const uint32_t llx = xl ? (uint32_t)((w64 << (oc + xm)) >> (64u - xl)) : 0u;
-                        ov = (1u << oc) + obits;
-                        ml = (L.mltab[mc] & 0xffffffu) + mlx;
-                        ll = (L.lltab[lc] & 0xffffffu) + llx;
+                    {
+                        const bool mine = lane < cn && lane < dec_bad;
+                        uint32_t my_el = 0, my_eo = 0, my_em = 0, my_tot = 0;
+                        if (mine) {
+                            my_el = *(const uint32_t *)((const char *)L.ll.e + L.xpar[3 * lane]);
+                            my_eo = *(const uint32_t *)((const char *)L.of.e + L.xpar[3 * lane + 1]);
+                            my_em = *(const uint32_t *)((const char *)L.ml.e + L.xpar[3 * lane + 2]);
+                            const uint32_t S = my_el + my_eo + my_em;
+                            my_tot = (S >> 5) & 127u;
+                            if (i0 + lane + 1 == nseq) my_tot -= S & 31u;
+                        }
+                        const int32_t my_top = T0 - (int32_t)(wave_incl_scan(my_tot) - my_tot);
+                        if (mine) {
+                            const uint32_t oc = (my_eo >> 12) & 63u, mc = (my_em >> 12) & 63u, lc = (my_el >> 12) & 63u;
+                            const uint32_t xl = ((my_el >> 5) & 127u) - (my_el & 31u), xm = ((my_em >> 5) & 127u) - (my_em & 31u);
+                            const int32_t q = my_top - 64;
+                            int32_t wi = (q >> 5) - s.win0;
+                            wi = wi < 0 ? 0 : (wi > 253 ? 253 : wi);
+                            const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
+                            const uint32_t sh = (uint32_t)q & 31u;
+                            const uint64_t w64 = ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32) | __builtin_amdgcn_alignbit(d1, d0, sh);
+                            const uint32_t obits = oc ? (uint32_t)(w64 >> (64u - oc)) : 0u;
+                            const uint32_t mlx = xm ? (uint32_t)((w64 << oc) >> (64u - xm)) : 0u;
+                            const uint32_t llx = xl ? (uint32_t)((w64 << (oc + xm)) >> (64u - xl)) : 0u;
+                            ov = (1u << oc) + obits;
+                            ml = (L.mltab[mc] & 0xffffffu) + mlx;
+                            ll = (L.lltab[lc] & 0xffffffu) + llx;
+                        }
                     }
                     // ---- offsets.  A sequence with a new offset (the usual case) is done in parallel; only the ones that
                     // use the repeat-offset history are walked in order, with the history brought up to date from the
