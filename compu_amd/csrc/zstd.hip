@@ -163,6 +163,14 @@ __device__ __forceinline__ uint32_t sq_read(ZLds &L, const Bits &b, SeqBits &s, 
     return v;
 }
 
+// (a << 2) + b in one instruction (the compiler emits a shift and an add)
+__device__ __forceinline__ uint32_t lshl2_add(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { return rd32_at(b, byte * 8u) & 0xffu; }
 
 // ---- four-stream Huffman literals, 16 lanes per stream -------------------------------------------------
@@ -433,41 +441,66 @@ __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, 
     return (int)used;
 }
 
-// FSE decoding table from normalized counts in L.norm (sec. 4.1.1).  Uniform; lane 0 writes.
+// FSE decoding table from normalized counts in L.norm (sec. 4.1.1), all lanes.  nsym <= 64: lane s keeps symbol s.
+// The reference procedure walks the table with a fixed odd step and hands the visited cells (those above `high`, which
+// hold the "less than one" symbols, are skipped) to the symbols in order.  Here every cell finds its symbol by itself:
+// the step's inverse modulo the size tells when a position is visited, the skipped positions visited earlier are
+// counted, and the symbol owning that cell number is found by bisection in the running sums of the counts.  The second
+// half (bit count and baseline from the rank of a state among the states of its symbol) goes 64 states at a time.
 __device__ int fse_build(ZLds &L, FseView t, int nsym, int al)
 {
     WSYNC();
-    const bool w = lane_id() == 0;
-    int size = 1 << al, high = size - 1;
-    for (int s = 0; s < nsym; s++) {
-        int c = L.norm[s];
-        if (c == -1) {
-            if (w) t.e[high] = (uint32_t)s;
-            high--;
-            if (w) L.next[s] = 1;
-        } else if (w) L.next[s] = (uint16_t)c;
-    }
-    int step = (size >> 1) + (size >> 3) + 3, mask = size - 1, pos = 0;
-    for (int s = 0; s < nsym; s++) {
-        int c = L.norm[s];
-        for (int i = 0; i < c; i++) {
-            if (w) t.e[pos] = (uint32_t)s;
-            do {
-                pos = (pos + step) & mask;
-            } while (pos > high);
-        }
-    }
-    if (pos != 0) return -1;
+    const uint32_t lane = lane_id();
+    const uint64_t lt = lanemask_lt();
+    const uint32_t size = 1u << al, mask = size - 1u;
+    const int c = (int)lane < nsym ? (int)L.norm[lane] : 0;
+    const uint64_t negm = __ballot(c == -1);
+    const uint32_t nneg = (uint32_t)__popcll(negm);
+    const uint32_t cnt = c > 0 ? (uint32_t)c : 0u;
+    const uint32_t incl = wave_incl_scan(cnt);
+    if (rdlane(incl, 63) + nneg != size) return -1;  // the walk would not end on cell 0
+    const uint32_t high = size - 1u - nneg;
+    if (c == -1) t.e[size - 1u - (uint32_t)__popcll(negm & lt)] = lane;
+    L.next[lane] = (uint16_t)(c == -1 ? 1u : cnt);
+    L.xheads[lane] = incl;  // (copy-phase scratch, free here)
+    const uint32_t step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t inv = step;  // Newton: correct bits double per round, 3 to begin with
+#pragma unroll
+    for (int i = 0; i < 3; i++) inv *= 2u - step * inv;
+    const uint32_t kq = lane < nneg ? ((size - 1u - lane) * inv) & mask : 0xffffffffu;  // when the skipped positions are visited
     WSYNC();
-    // each state's bit count and baseline depend on how many earlier states share its symbol
-    if (w) {
-        for (int u = 0; u < size; u++) {
-            uint32_t s = t.e[u] & 0xffu;
-            uint32_t ns = L.next[s];
-            L.next[s] = (uint16_t)(ns + 1);
-            uint32_t nb = (uint32_t)al - (31u - (uint32_t)__clz((int)ns));
-            t.e[u] = s | (nb << 6) | ((((ns << nb) - (uint32_t)size) & 0xffffu) << 16);
+    for (uint32_t p = lane; p <= high; p += 64) {
+        const uint32_t k = (p * inv) & mask;
+        uint32_t skipped = 0;
+        for (uint32_t i = 0; i < nneg; i++) skipped += rdlane(kq, i) < k ? 1u : 0u;
+        const uint32_t cell = k - skipped;
+        uint32_t sym = 0;  // symbols whose running sum is <= cell
+#pragma unroll
+        for (uint32_t h = 32; h; h >>= 1)
+            if (L.xheads[sym + h - 1u] <= cell) sym += h;
+        t.e[p] = sym;
+    }
+    WSYNC();
+    for (uint32_t u0 = 0; u0 < size; u0 += 64) {
+        const uint32_t u = u0 + lane;
+        const bool in = u < size;
+        const uint32_t sy = in ? t.e[u] & 0xffu : 0u;
+        uint64_t same = __ballot(in);  // lanes of this round with the same symbol
+#pragma unroll
+        for (uint32_t bit = 0; bit < 6; bit++) {
+            const uint64_t bm = __ballot((sy >> bit) & 1u);
+            same &= ((sy >> bit) & 1u) ? bm : ~bm;
         }
+        if (in) {
+            const uint32_t ns = (uint32_t)L.next[sy] + (uint32_t)__popcll(same & lt);
+            const uint32_t nb = (uint32_t)al - (31u - (uint32_t)__clz((int)ns));
+            t.e[u] = sy | (nb << 6) | ((((ns << nb) - size) & 0xffffu) << 16);
+        }
+        WSYNC();
+        if (in && (same >> lane) == 1ull) L.next[sy] = (uint16_t)(L.next[sy] + (uint32_t)__popcll(same));  // the group's highest lane
+        WSYNC();
+    }
+    if (lane == 0) {
         *t.al = (uint32_t)al;
         *t.valid = 1;
     }
@@ -1164,7 +1197,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     const int32_t T0 = (int32_t)s.lo + s.avail, Tmin = (int32_t)s.lo;
                     int32_t T = T0;
                     __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
-                    for (uint32_t j = 0; j < cn; j++) {
+                    for (uint32_t j = 0; j < n_upd; j++) {
                         int32_t wi = ((T - 64) >> 5) - s.win0;
                         wi = wi < 0 ? 0 : wi;
                         const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
@@ -1174,12 +1207,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         L.xpar[3 * j + 1] = ao;
                         L.xpar[3 * j + 2] = am;
                         const uint32_t S = el + eo + em;  // [4:0] the three state-bit counts, [11:5] those + the extra bits
-                        uint32_t tot = (S >> 5) & 127u;
-                        if (j >= n_upd) {  // the block's last sequence: extras only
-                            T -= (int32_t)(tot - (S & 31u));
-                            if (T < Tmin) dec_bad = j;
-                            break;
-                        }
+                        const uint32_t tot = (S >> 5) & 127u;
                         uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)T), wlo = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)T);
                         uint32_t x = 64u - tot;
                         if (tot > 64u) {
@@ -1194,14 +1222,24 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             x = 64u - n3;
                         }
                         const uint32_t W = (uint32_t)((((uint64_t)whi << 32) | wlo) >> (x & 63u));  // LL, ML, OF state bits, OF lowest
-                        al = (__builtin_amdgcn_ubfe(el, 23, 9) + __builtin_amdgcn_ubfe(W, eo + em, el)) << 2;
-                        am = (__builtin_amdgcn_ubfe(em, 23, 9) + __builtin_amdgcn_ubfe(W, eo, em)) << 2;
-                        ao = (__builtin_amdgcn_ubfe(eo, 23, 9) + __builtin_amdgcn_ubfe(W, 0, eo)) << 2;
+                        // next state = baseline + bits; entry bits [22:18] are zero, so entry >> 21 is the baseline times four
+                        al = lshl2_add(__builtin_amdgcn_ubfe(W, eo + em, el), el >> 21);
+                        am = lshl2_add(__builtin_amdgcn_ubfe(W, eo, em), em >> 21);
+                        ao = lshl2_add(__builtin_amdgcn_ubfe(W, 0, eo), eo >> 21);
                         T -= (int32_t)tot;
                         if (T < Tmin) {
                             dec_bad = j;
                             break;
                         }
+                    }
+                    if (dec_bad == 64 && n_upd < cn) {  // the block's last sequence: extras only, no state update
+                        const uint32_t S = *(const uint32_t *)((const char *)L.ll.e + al) + *(const uint32_t *)((const char *)L.of.e + ao) +
+                                           *(const uint32_t *)((const char *)L.ml.e + am);
+                        L.xpar[3 * n_upd] = al;
+                        L.xpar[3 * n_upd + 1] = ao;
+                        L.xpar[3 * n_upd + 2] = am;
+                        T -= (int32_t)(((S >> 5) & 127u) - (S & 31u));
+                        if (T < Tmin) dec_bad = n_upd;
                     }
                     __builtin_amdgcn_s_setprio(0);
                     s.avail = T - (int32_t)s.lo;
