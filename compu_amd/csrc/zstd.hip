@@ -1191,11 +1191,12 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     // States are kept as byte offsets into their tables.  Per sequence: six LDS reads in flight together
                     // (the 64 bits below the read position and the three entries), one add of the entries gives the bits
                     // consumed, one 64-bit shift brings the state bits to the bottom, three v_bfe with the entries
-                    // themselves as width / offset operands cut them, and the three state offsets are parked in LDS
-                    // for the lane that finishes the sequence.  The last sequence of a block updates no state.
+                    // themselves as width / offset operands cut them, and lane j keeps the three state offsets of sequence j
+                    // to finish it afterwards.  The last sequence of a block updates no state.
                     const uint32_t n_upd = i0 + cn == nseq ? cn - 1u : cn;
                     const int32_t T0 = (int32_t)s.lo + s.avail, Tmin = (int32_t)s.lo;
                     int32_t T = T0;
+                    uint32_t my_al = 0, my_ao = 0, my_am = 0;
                     __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
                     for (uint32_t j = 0; j < n_upd; j++) {
                         int32_t wi = ((T - 64) >> 5) - s.win0;
@@ -1203,9 +1204,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
                         const uint32_t el = *(const uint32_t *)((const char *)L.ll.e + al), eo = *(const uint32_t *)((const char *)L.of.e + ao),
                                        em = *(const uint32_t *)((const char *)L.ml.e + am);
-                        L.xpar[3 * j] = al;
-                        L.xpar[3 * j + 1] = ao;
-                        L.xpar[3 * j + 2] = am;
+                        my_al = lane == j ? al : my_al;  // lane j finishes sequence j
+                        my_ao = lane == j ? ao : my_ao;
+                        my_am = lane == j ? am : my_am;
                         const uint32_t S = el + eo + em;  // [4:0] the three state-bit counts, [11:5] those + the extra bits
                         const uint32_t tot = (S >> 5) & 127u;
                         uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)T), wlo = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)T);
@@ -1235,14 +1236,17 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     if (dec_bad == 64 && n_upd < cn) {  // the block's last sequence: extras only, no state update
                         const uint32_t S = *(const uint32_t *)((const char *)L.ll.e + al) + *(const uint32_t *)((const char *)L.of.e + ao) +
                                            *(const uint32_t *)((const char *)L.ml.e + am);
-                        L.xpar[3 * n_upd] = al;
-                        L.xpar[3 * n_upd + 1] = ao;
-                        L.xpar[3 * n_upd + 2] = am;
+                        my_al = lane == n_upd ? al : my_al;
+                        my_ao = lane == n_upd ? ao : my_ao;
+                        my_am = lane == n_upd ? am : my_am;
                         T -= (int32_t)(((S >> 5) & 127u) - (S & 31u));
                         if (T < Tmin) dec_bad = n_upd;
                     }
                     __builtin_amdgcn_s_setprio(0);
                     s.avail = T - (int32_t)s.lo;
+#ifdef CHIP_EXP_CHAINONLY
+                    if (my_al != 0xffffffffu) continue;
+#endif
                     // ---- parallel part: lane j reads sequence j's entries again, finds its bit position by a prefix sum of
                     // the bits consumed, cuts the extra bits from the window and forms the values
                     uint32_t ov = 4;
@@ -1250,9 +1254,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         const bool mine = lane < cn && lane < dec_bad;
                         uint32_t my_el = 0, my_eo = 0, my_em = 0, my_tot = 0;
                         if (mine) {
-                            my_el = *(const uint32_t *)((const char *)L.ll.e + L.xpar[3 * lane]);
-                            my_eo = *(const uint32_t *)((const char *)L.of.e + L.xpar[3 * lane + 1]);
-                            my_em = *(const uint32_t *)((const char *)L.ml.e + L.xpar[3 * lane + 2]);
+                            my_el = *(const uint32_t *)((const char *)L.ll.e + my_al);
+                            my_eo = *(const uint32_t *)((const char *)L.of.e + my_ao);
+                            my_em = *(const uint32_t *)((const char *)L.ml.e + my_am);
                             const uint32_t S = my_el + my_eo + my_em;
                             my_tot = (S >> 5) & 127u;
                             if (i0 + lane + 1 == nseq) my_tot -= S & 31u;
