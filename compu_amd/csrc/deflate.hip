@@ -578,15 +578,36 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             const uint64_t limmask = lim64 >= 64 ? ~0ull : ((1ull << lim64) - 1ull);
             const uint64_t cand = __ballot(mlen >= MIN_MATCH) & limmask;
             uint64_t covered = 0;  // positions inside a chosen match (its start excluded)
-            uint32_t pos = skip;
-            while (pos < lim64) {
-                const uint64_t rest = cand & (~0ull << pos);
-                if (!rest) break;  // literals up to the end of the chunk
-                const uint32_t c = (uint32_t)__builtin_ctzll(rest);
-                const uint32_t len = rdlane(mlen, c);
-                pos = c + len;
-                const uint32_t room = 63u - c, size = len - 1u < room ? len - 1u : room;
-                covered |= ((1ull << size) - 1ull) << ((c + 1u) & 63u);  // `size` ones from bit c+1 (none when c = 63)
+            uint32_t pos = rdfirst(skip);
+            {
+                const uint32_t lim_s = rdfirst(lim64);
+                const uint64_t cand_s = ((uint64_t)rdfirst((uint32_t)(cand >> 32)) << 32) | rdfirst((uint32_t)cand);
+                // while (pos < lim64) { rest = cand & (~0 << pos); if (!rest) break; c = ctz(rest); len = mlen of lane c;
+                //   pos = c + len; covered |= min(len - 1, 63 - c) ones from bit c + 1; }   -- 14 scalar instructions per chosen
+                // match (the compiler's version of the same loop: 19)
+                uint64_t t, m;
+                uint32_t c, len, sz, room;
+                asm volatile(
+                    "1:\n\t"
+                    "s_cmp_ge_u32 %[pos], %[lim]\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "s_lshl_b64 %[t], -1, %[pos]\n\t"
+                    "s_and_b64 %[t], %[t], %[cand]\n\t"
+                    "s_cbranch_scc0 2f\n\t"
+                    "s_ff1_i32_b64 %[c], %[t]\n\t"
+                    "v_readlane_b32 %[len], %[mlen], %[c]\n\t"
+                    "s_add_u32 %[pos], %[c], %[len]\n\t"
+                    "s_xor_b32 %[room], %[c], 63\n\t"
+                    "s_add_u32 %[sz], %[len], -1\n\t"
+                    "s_min_u32 %[sz], %[sz], %[room]\n\t"
+                    "s_add_u32 %[c], %[c], 1\n\t"
+                    "s_bfm_b64 %[m], %[sz], %[c]\n\t"
+                    "s_or_b64 %[cov], %[cov], %[m]\n\t"
+                    "s_branch 1b\n\t"
+                    "2:"
+                    : [pos] "+s"(pos), [cov] "+s"(covered), [t] "=&s"(t), [m] "=&s"(m), [c] "=&s"(c), [len] "=&s"(len), [sz] "=&s"(sz), [room] "=&s"(room)
+                    : [lim] "s"(lim_s), [cand] "s"(cand_s), [mlen] "v"(mlen)
+                    : "scc");
             }
             const uint64_t sel = skip < 64 ? limmask & ~covered & (~0ull << skip) : 0ull;
             skip = pos > 64 ? pos - 64 : 0;

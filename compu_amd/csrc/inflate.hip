@@ -99,7 +99,8 @@ constexpr bool seg_magic_ok()
         if (((x * SEG_MAGIC) >> SEG_SHIFT) != x / S_BITS) return false;
     return true;
 }
-static_assert(seg_magic_ok() && (64u * S_BITS + 4096u) * (uint64_t)SEG_MAGIC < (1ull << 32), "segment index by multiplication");
+static_assert(seg_magic_ok() && (64u * S_BITS + 4096u) * (uint64_t)SEG_MAGIC < (1ull << 32) && SEG_MAGIC < (1u << 24) && 64u * S_BITS + 4096u < (1u << 24),
+              "segment index by multiplication");
 constexpr int IN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
 static_assert(IN_DW >= 320, "table-build scratch lives in the input window");
 constexpr size_t SCRATCH_WORDS_PER_WAVE = (size_t)64 * ROW_TOKENS;
@@ -844,8 +845,9 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                 // the boundary at p: marked in the lane's own row, looked up in the row of the segment's owner elsewhere
                 // (segment and offset inside it by a multiplication; a stopped lane keeps a harmless index)
                 const uint32_t rel = p - B;
-                const uint32_t seg = ((rel * SEG_MAGIC) >> SEG_SHIFT) & 63u;
-                const uint32_t off = rel - seg * (uint32_t)S_BITS;
+                // (24-bit multiplies: full rate; v_mul_lo_u32 takes four times as long.  rel and SEG_MAGIC are below 2^24)
+                const uint32_t seg = (__umul24(rel, SEG_MAGIC) >> SEG_SHIFT) & 63u;
+                const uint32_t off = rel - __umul24(seg, (uint32_t)S_BITS);
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&L.rows[(off >> 5) * 64 + seg], (active && seg == lane) ? bit : 0u);
                 const bool joined = active && seg != lane && (old & bit);
