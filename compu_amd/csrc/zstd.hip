@@ -681,7 +681,8 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
 }
 
 // XXH64 (seed 0) of p[0..n): lanes 0..3 own the four accumulators.  Returns the low 32 bits.
-__device__ uint32_t wave_xxh64_low32(const uint8_t *p, uint32_t n)
+// `stage`: 512 qwords of LDS scratch (anything that is dead once the frame's blocks are done).
+__device__ uint32_t wave_xxh64_low32(uint64_t *stage, const uint8_t *p, uint32_t n)
 {
     constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
                        P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
@@ -700,18 +701,32 @@ __device__ uint32_t wave_xxh64_low32(const uint8_t *p, uint32_t n)
     if (n >= 32) {
         uint64_t acc = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ULL : 0ULL - P1;
         const uint32_t stripes = n >> 5;
-        if (lane < 4) {
-            // the accumulator recurrence is serial; the loads are not: eight stripes are fetched at a time
-            uint32_t i = 0;
-            for (; i + 8 <= stripes; i += 8) {
-                uint64_t in[8];
+        // The accumulator recurrence acc = rotl(acc + in * P2, 31) * P1 is serial per 8-byte column, but the products
+        // in * P2 are not: all 64 lanes form them for 128 stripes at a time into `stage` (4 KB of LDS), then lanes 0..3
+        // run their columns over the staged products -- one multiplication per dependent step instead of two, and no
+        // address arithmetic or loads on the chain.
+        for (uint32_t s0 = 0; s0 < stripes; s0 += 128) {
+            const uint32_t ns = stripes - s0 < 128 ? stripes - s0 : 128;
+            WSYNC();
 #pragma unroll
-                for (uint32_t k = 0; k < 8; k++) in[k] = rd64(32u * (i + k) + 8u * lane);
-#pragma unroll
-                for (uint32_t k = 0; k < 8; k++) acc = round1(acc, in[k]);
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t q = 64u * k + lane;  // qword of the batch: stripe q / 4, column q % 4
+                if (q < 4u * ns) stage[q] = rd64(32u * s0 + 8u * q) * P2;
             }
-            for (; i < stripes; i++) acc = round1(acc, rd64(32u * i + 8u * lane));
+            WSYNC();
+            if (lane < 4) {
+                uint32_t i = 0;
+                for (; i + 8 <= ns; i += 8) {
+                    uint64_t in[8];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) in[k] = stage[4u * (i + k) + lane];
+#pragma unroll
+                    for (uint32_t k = 0; k < 8; k++) acc = rotl(acc + in[k], 31) * P1;
+                }
+                for (; i < ns; i++) acc = rotl(acc + stage[4u * i + lane], 31) * P1;
+            }
         }
+        WSYNC();
         off = stripes << 5;
         uint64_t v[4];
         for (int k = 0; k < 4; k++) {
@@ -1481,7 +1496,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         if (END - ip < 4) ZNEED_INPUT();
         uint32_t want = rd32_at(b, ip * 8u);
 #ifndef CHIP_EXP_NOXXH
-        if (wave_xxh64_low32(gout, opos) != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);
+        if (wave_xxh64_low32((uint64_t *)L.huf, gout, opos) != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);  // the Huffman table is dead by now
 #endif
         ip += 4;
     }
