@@ -833,8 +833,15 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         const uint32_t s = B + lane * S_BITS;
         uint32_t lim = s + S_BITS + xt_bits;
         if (lim > B + 64u * S_BITS) lim = B + 64u * S_BITS;  // nobody to join behind the last segment
-        uint32_t p = s, nst = 0, reason = R_LIMIT, jl = 64, aux = s;
+        // Why a lane stopped is worked out once, after the loop: a stopped lane's position no longer moves, so the straight-line
+        // decode of every later step (all lanes run it) reproduces the stopping step's entries; per step only the running
+        // state (position, token count, three lane masks) is updated.
+        uint32_t p = s, nst = 0;
         bool active = s < end_bit;
+        bool by_limit = !active;   // stopped because its chain simply ended (or never ran): nothing to report
+        bool by_join = false;      // stopped on a boundary already marked by that segment's owner
+        uint32_t seg = lane, cl = 0, kind = K_LIT, kind2 = K_LIT, tb = 0;
+        bool islen = false;
         while (__any(active)) {
             STAT_ADD(11, 1);
             uint32_t t4[4];
@@ -846,7 +853,7 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                 // (segment and offset inside it by a multiplication; a stopped lane keeps a harmless index)
                 const uint32_t rel = p - B;
                 // (24-bit multiplies: full rate; v_mul_lo_u32 takes four times as long.  rel and SEG_MAGIC are below 2^24)
-                const uint32_t seg = (__umul24(rel, SEG_MAGIC) >> SEG_SHIFT) & 63u;
+                seg = (__umul24(rel, SEG_MAGIC) >> SEG_SHIFT) & 63u;
                 const uint32_t off = rel - __umul24(seg, (uint32_t)S_BITS);
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&L.rows[(off >> 5) * 64 + seg], (active && seg == lane) ? bit : 0u);
@@ -857,34 +864,37 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
                 win_bits(L, w, p, lo, hi);
                 uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
                 if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, L.lit_h, L.lit_sorted);
-                const uint32_t cl = e & 15u, eb = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+                cl = e & 15u;
+                const uint32_t eb = (e >> 4) & 15u;
+                kind = (e >> 8) & 3u;
                 const uint32_t n1 = cl + eb;
-                const bool islen = kind == K_LEN;
+                islen = kind == K_LEN;
                 const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
                 uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
                 if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, L.dist_h, L.dist_sorted);
                 const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-                const uint32_t tb = n1 + (islen ? cl2 + eb2 : 0u);
+                kind2 = (e2 >> 8) & 3u;
+                tb = n1 + (islen ? cl2 + eb2 : 0u);
                 t4[j] = islen ? tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2)) : tok_lit(e >> 16);
-                // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
-                uint32_t st = R_RUN;
-                st = (kind == K_BAD || (islen && ((e2 >> 8) & 3u) == K_BAD)) ? (uint32_t)R_BAD : st;
-                st = kind == K_EOB ? (uint32_t)R_EOB : st;
-                st = p + tb > end_bit ? (uint32_t)R_NEED_INPUT : st;
-                st = joined ? (uint32_t)R_JOIN : st;
-                const bool go = active && st == R_RUN;
-                if (active && !go) {
-                    reason = st;
-                    jl = seg;
-                    aux = st == R_EOB ? p + cl : p;  // behind the end-of-block code / where the chains met
-                }
+                // end of block / invalid code (kinds 2 and 3), invalid distance code, input exhausted inside the token
+                const bool halt = kind >= K_EOB || (islen && kind2 == K_BAD) || p + tb > end_bit;
+                const bool go = active && !joined && !halt;
+                by_join = by_join || joined;
                 nst += go ? 1u : 0u;
                 p += go ? tb : 0u;
                 active = go && p < lim && nst < (uint32_t)ROW_TOKENS;
-                if (go && !active) aux = p;  // reason stays R_LIMIT: the chain simply ends here
+                by_limit = by_limit || (go && !active);  // the chain simply ends here
             }
             if (was && nst > q0) *(uint4 *)(myrow + 8u * q0) = make_uint4(t4[0], t4[1], t4[2], t4[3]);  // q0 is a multiple of 4: row_word(q0)
         }
+        // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
+        uint32_t reason = R_BAD;
+        reason = kind == K_EOB ? (uint32_t)R_EOB : reason;
+        reason = p + tb > end_bit ? (uint32_t)R_NEED_INPUT : reason;
+        reason = by_join ? (uint32_t)R_JOIN : reason;
+        reason = by_limit ? (uint32_t)R_LIMIT : reason;
+        const uint32_t jl = seg;
+        const uint32_t aux = reason == R_EOB ? p + cl : p;  // behind the end-of-block code / where the chains met / where the chain ends
         WSYNC();  // rows complete; token stores have landed (the barrier's release waits for them)
         STAT_ACC(2);
         // ---- the true stream: lane 0's chain, then the chain it joined from the join on, and so on ----
