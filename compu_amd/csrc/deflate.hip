@@ -3,7 +3,7 @@
 // Replaces, per unit, what compu reaches through sys::deflate (src/encoder/mod.rs:352) for an encoder
 // built by Interface::zlib_ng(ZlibOptions) (src/encoder/zlib_ng.rs:50-87): greedy hash matching in a
 // 32 KiB window; level 1 writes one fixed-Huffman block (the shape of zlib-ng's deflate_quick; BASELINE
-// configs[3]), levels 2..9 dynamic-Huffman blocks; gzip / zlib wrappers with CRC-32 / Adler-32 trailers.
+// configs[3]), levels 2..9 dynamic-Huffman blocks (4..9 with lazy choice); gzip / zlib wrappers with CRC-32 / Adler-32 trailers.
 // compu's own tests pin the encoder by round trip and cross-API determinism only (tests/encoder.rs:10-78);
 // the exact algorithm is stated in oracle/oracle_deflate.c and these kernels reproduce its output byte for byte.
 //
@@ -60,17 +60,6 @@ __device__ __forceinline__ uint32_t first_diff16(const U128u a, const U128u b)
 
 __device__ __forceinline__ uint32_t rev_bits(uint32_t v, uint32_t n) { return __brev(v) >> (32 - n); }
 
-// RFC 1951 sec. 3.2.5 / 3.2.6: one token as LSB-first bits (<= 31)
-__device__ __forceinline__ uint32_t lit_code(uint32_t v, uint32_t &n)
-{
-    if (v < 144) {
-        n = 8;
-        return rev_bits(0x30 + v, 8);
-    }
-    n = 9;
-    return rev_bits(0x190 + (v - 144), 9);
-}
-
 // RFC 1951 sec. 3.2.5: length -> code 0..28 (symbol 257 + code), extra-bit count and value
 __device__ __forceinline__ void len_parts(uint32_t len, uint32_t &lc, uint32_t &lext, uint32_t &lxv)
 {
@@ -103,29 +92,6 @@ __device__ __forceinline__ void dist_parts(uint32_t dist, uint32_t &dc, uint32_t
     dext = (h > 1u ? h : 1u) - 1u;                              // 0..13
     dc = 2u * h + ((y >> dext) & 1u);
     dxv = y & ~(~0u << dext);
-}
-
-__device__ __forceinline__ uint32_t match_code(uint32_t len, uint32_t dist, uint32_t &n)
-{
-    uint32_t lc, lext, lxv, dc, dext, dxv;
-    len_parts(len, lc, lext, lxv);
-    dist_parts(dist, dc, dext, dxv);
-    uint32_t sym = 257 + lc, bits, nb;
-    if (sym < 280) {
-        bits = rev_bits(sym - 256, 7);
-        nb = 7;
-    } else {
-        bits = rev_bits(0xC0 + (sym - 280), 8);
-        nb = 8;
-    }
-    bits |= lxv << nb;
-    nb += lext;
-    bits |= rev_bits(dc, 5) << nb;
-    nb += 5;
-    bits |= dxv << nb;
-    nb += dext;
-    n = nb;
-    return bits;
 }
 
 struct EncArgs {
@@ -427,6 +393,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
     const bool hdr = a.flags & 1u, trl = a.flags & 2u, final = a.flags & 4u;
     const uint32_t strategy = (a.flags >> 8) & 7u;
     const bool no_match = strategy == CHIP_STRATEGY_HUFFMAN_ONLY, rle = strategy == CHIP_STRATEGY_RLE;
+    const bool lazy = a.level >= 4;  // (dynamic levels only: zlib's lazy matching starts at level 4 too)
     const int fmt = a.b.format;
 
     const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);
@@ -578,6 +545,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             const uint64_t limmask = lim64 >= 64 ? ~0ull : ((1ull << lim64) - 1ull);
             const uint64_t cand = __ballot(mlen >= MIN_MATCH) & limmask;
             uint64_t covered = 0;  // positions inside a chosen match (its start excluded)
+            uint64_t deferred = 0;  // lazy levels: match candidates that gave way to the next position and became literals
             uint32_t pos = rdfirst(skip);
             {
                 const uint32_t lim_s = rdfirst(lim64);
@@ -587,6 +555,43 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 // match (the compiler's version of the same loop: 19)
                 uint64_t t, m;
                 uint32_t c, len, sz, room;
+                if (DYN && lazy) {
+                    // levels 4..9: a match gives way to a longer one at the next position of the chunk (it becomes a literal)
+                    uint32_t len1;
+                    asm volatile(
+                        "1:\n\t"
+                        "s_cmp_ge_u32 %[pos], %[lim]\n\t"
+                        "s_cbranch_scc1 3f\n\t"
+                        "s_lshl_b64 %[t], -1, %[pos]\n\t"
+                        "s_and_b64 %[t], %[t], %[cand]\n\t"
+                        "s_cbranch_scc0 3f\n\t"
+                        "s_ff1_i32_b64 %[c], %[t]\n\t"
+                        "v_readlane_b32 %[len], %[mlen], %[c]\n\t"
+                        "s_add_u32 %[sz], %[c], 1\n\t"
+                        "s_cmp_ge_u32 %[sz], %[lim]\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "v_readlane_b32 %[len1], %[mlen], %[sz]\n\t"
+                        "s_cmp_gt_u32 %[len1], %[len]\n\t"
+                        "s_cbranch_scc0 2f\n\t"
+                        "s_lshl_b64 %[t], 1, %[c]\n\t"
+                        "s_or_b64 %[def], %[def], %[t]\n\t"
+                        "s_mov_b32 %[pos], %[sz]\n\t"
+                        "s_branch 1b\n\t"
+                        "2:\n\t"
+                        "s_add_u32 %[pos], %[c], %[len]\n\t"
+                        "s_xor_b32 %[room], %[c], 63\n\t"
+                        "s_add_u32 %[sz], %[len], -1\n\t"
+                        "s_min_u32 %[sz], %[sz], %[room]\n\t"
+                        "s_add_u32 %[c], %[c], 1\n\t"
+                        "s_bfm_b64 %[m], %[sz], %[c]\n\t"
+                        "s_or_b64 %[cov], %[cov], %[m]\n\t"
+                        "s_branch 1b\n\t"
+                        "3:"
+                        : [pos] "+s"(pos), [cov] "+s"(covered), [t] "=&s"(t), [m] "=&s"(m), [c] "=&s"(c), [len] "=&s"(len), [sz] "=&s"(sz), [room] "=&s"(room),
+                          [len1] "=&s"(len1), [def] "+s"(deferred)
+                        : [lim] "s"(lim_s), [cand] "s"(cand_s), [mlen] "v"(mlen)
+                        : "scc");
+                } else {
                 asm volatile(
                     "1:\n\t"
                     "s_cmp_ge_u32 %[pos], %[lim]\n\t"
@@ -608,6 +613,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     : [pos] "+s"(pos), [cov] "+s"(covered), [t] "=&s"(t), [m] "=&s"(m), [c] "=&s"(c), [len] "=&s"(len), [sz] "=&s"(sz), [room] "=&s"(room)
                     : [lim] "s"(lim_s), [cand] "s"(cand_s), [mlen] "v"(mlen)
                     : "scc");
+                }
             }
             const uint64_t sel = skip < 64 ? limmask & ~covered & (~0ull << skip) : 0ull;
             skip = pos > 64 ? pos - 64 : 0;
@@ -641,7 +647,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 // tokens to the scratch in order, symbol counts to LDS
                 if (mine) {
                     uint32_t t = v & 0xffu;
-                    if (mlen >= MIN_MATCH) {
+                    if (mlen >= MIN_MATCH && !((deferred >> lane) & 1ull)) {
                         uint32_t dc, dext, dxv;
                         const uint32_t e = L.lentab[mlen - 3u];
                         dist_parts(mdist, dc, dext, dxv);

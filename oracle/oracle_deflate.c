@@ -16,7 +16,8 @@
  * bytes, distance <= 32768), then the table takes the highest position per slot.  Tokens are chosen
  * greedily left to right.  Level 1 (and Z_FIXED): emitted with the fixed Huffman code (RFC 1951
  * sec. 3.2.6); a segment whose fixed-Huffman form is not smaller than stored blocks is emitted stored.
- * Levels 2..9: the same tokens in dynamic-Huffman blocks (write_block below).  Level 0 = stored.
+ * Levels 2..9: dynamic-Huffman blocks (write_block below); from level 4 on the choice is lazy: a match
+ * gives way to a longer one at the next position of the same chunk.  Level 0 = stored.
  */
 #include "oracle.h"
 
@@ -98,7 +99,7 @@ typedef struct { uint32_t table[1u << HASH_BITS]; size_t skip; } matcher;
 
 /* Greedy tokens of the chunk [base, base+64) of in[0..n), appended to tok (a literal is its byte, a match
  * TOK_MATCH | (dist-1) << 9 | (len-3)); a match may run past the chunk, m->skip carries the overrun. */
-static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t base, int strategy, uint32_t *tok)
+static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t base, int strategy, int lazy, uint32_t *tok)
 {
     unsigned mlen[64], mdist[64], nt = 0;
     uint32_t hh[64];
@@ -126,7 +127,9 @@ static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t bas
         if (hh[l] != 0xffffffffu && table[hh[l]] < base + l + 1) table[hh[l]] = (uint32_t)(base + l + 1);
     size_t pos = m->skip;
     while (pos < 64 && base + pos < n) {
-        if (mlen[pos] >= MIN_MATCH) { tok[nt++] = TOK_MATCH | ((mdist[pos] - 1) << 9) | (mlen[pos] - 3); pos += mlen[pos]; }
+        /* lazy (levels 4..9, like zlib from level 4 on): a match gives way to a longer one at the next position of the chunk */
+        const int defer = lazy && pos + 1 < 64 && base + pos + 1 < n && mlen[pos + 1] > mlen[pos];
+        if (mlen[pos] >= MIN_MATCH && !defer) { tok[nt++] = TOK_MATCH | ((mdist[pos] - 1) << 9) | (mlen[pos] - 3); pos += mlen[pos]; }
         else { tok[nt++] = in[base + pos]; pos += 1; }
     }
     m->skip = pos > 64 ? pos - 64 : 0;
@@ -313,7 +316,7 @@ static void write_block(bitw *w, const uint32_t *tok, unsigned nt, const uint8_t
     bw_put(w, lc_[256], L[256]);
 }
 
-static size_t encode_segment_dynamic(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int strategy, int final, int *overflow)
+static size_t encode_segment_dynamic(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int level, int strategy, int final, int *overflow)
 {
     bitw w = {out, cap, 0, 0, 0, 0};
     matcher *m = (matcher *)calloc(1, sizeof *m);
@@ -321,7 +324,7 @@ static size_t encode_segment_dynamic(const uint8_t *in, size_t n, uint8_t *out, 
     unsigned nt = 0;
     size_t from = 0, base = 0;
     for (;;) {
-        if (base < n) { nt += chunk_tokens(m, in, n, base, strategy, tok + nt); base += 64; }
+        if (base < n) { nt += chunk_tokens(m, in, n, base, strategy, level >= 4, tok + nt); base += 64; }
         const int ended = base >= n;
         if (ended || nt > TOK_BLOCK - 64) {
             size_t to = ended ? n : base + m->skip;
@@ -347,7 +350,7 @@ static size_t encode_segment_dynamic(const uint8_t *in, size_t n, uint8_t *out, 
  * marker (!final).  Returns the size; *overflow is set when cap was too small. */
 static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t cap, int level, int strategy, int final, int *overflow)
 {
-    if (level >= 2 && strategy != 4) return encode_segment_dynamic(in, n, out, cap, strategy, final, overflow);
+    if (level >= 2 && strategy != 4) return encode_segment_dynamic(in, n, out, cap, level, strategy, final, overflow);
     bitw w = {out, cap, 0, 0, 0, 0};
     size_t ssz = stored_size(n, !final);
     int use_stored = level == 0;
@@ -356,7 +359,7 @@ static size_t encode_segment(const uint8_t *in, size_t n, uint8_t *out, size_t c
         bw_put(&w, (uint32_t)(final ? 1 : 0) | (1u << 1), 3);
         for (size_t base = 0; base < n; base += 64) {
             uint32_t tok[64];
-            unsigned nt = chunk_tokens(m, in, n, base, strategy, tok);
+            unsigned nt = chunk_tokens(m, in, n, base, strategy, 0, tok);
             for (unsigned i = 0; i < nt; i++) {
                 int nb;
                 uint32_t bits = (tok[i] & TOK_MATCH) ? match_bits(TOK_LEN(tok[i]), TOK_DIST(tok[i]), &nb) : lit_bits(tok[i], &nb);
