@@ -1364,18 +1364,20 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         ZFAIL(ZSTD_E_CORRUPTION);
                     }
                     const uint32_t LB = rdlane(lit_incl, 63), OB = rdlane(out_incl, 63);
+                    // (LSYNC in both phases: the steps talk through LDS, and a wave's global stores are seen by its later loads in
+                    // program order -- lanes of one wave share the CU's L1 --, so no step waits for its stores to be acknowledged)
                     // ---- phase A: all literal bytes of the chunk (their sources never depend on this chunk) ----
 #ifndef CHIP_EXP_NOEXEC
                     if (LB) {
-                        WSYNC();
+                        LSYNC();
                         L.xpar[2 * lane] = ostart;
                         L.xpar[2 * lane + 1] = lit_before;
                         uint32_t carry = 0;
                         for (uint32_t wb = 0; wb < LB; wb += 256) {
                             L.xheads[lane] = 0;
-                            WSYNC();
+                            LSYNC();
                             if (ll && lit_before >= wb && lit_before < wb + 256) ((uint8_t *)L.xheads)[lit_before - wb] = (uint8_t)(lane + 1);
-                            WSYNC();
+                            LSYNC();
                             const uint32_t h = L.xheads[lane];
                             uint32_t r0 = h & 0xffu, r1 = (h >> 8) & 0xffu, r2 = (h >> 16) & 0xffu, r3 = h >> 24;
                             r1 = r1 > r0 ? r1 : r0;
@@ -1400,10 +1402,14 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                                 dsts[j] = L.xpar[2 * o] + (q - L.xpar[2 * o + 1]);
                                 bytes[j] = lit_mode == 1 ? (uint8_t)lit_rle : litsrc[has[j] ? lpos + q : 0u];
                             }
+                            // the four bytes are put together before the first store: one wait for the loads, and none between
+                            // the stores (a wait in front of every conditional store would also wait for the store before it)
+                            uint32_t packed = (uint32_t)bytes[0] | ((uint32_t)bytes[1] << 8) | ((uint32_t)bytes[2] << 16) | ((uint32_t)bytes[3] << 24);
+                            asm volatile("" : "+v"(packed));  // (keeps the compiler from storing the loaded bytes one by one after all)
 #pragma unroll
                             for (int j = 0; j < 4; j++)
-                                if (has[j]) gout[dsts[j]] = bytes[j];
-                            WSYNC();
+                                if (has[j]) gout[dsts[j]] = (uint8_t)(packed >> (8 * j));
+                            LSYNC();
                         }
                     }
                     // ---- phase B: matches, several per step as long as none reads what the step writes ----------
@@ -1425,7 +1431,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
                             const uint32_t nbytes = rdlane(mbi, lastl) - b0;
                             L.xheads[lane] = 0;
-                            WSYNC();
+                            LSYNC();
                             if ((inc >> lane) & 1ull) {
                                 const uint32_t rank = (uint32_t)__popcll(inc & lanemask_lt());
                                 const uint32_t rel = mbx - b0;
@@ -1434,7 +1440,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                                 L.xpar[3 * rank + 1] = off;
                                 L.xpar[3 * rank + 2] = (ml - 1u) | (rel << 8);
                             }
-                            WSYNC();
+                            LSYNC();
                             const uint32_t h = L.xheads[lane];
                             uint32_t r0 = h & 0xffu, r1 = (h >> 8) & 0xffu, r2 = (h >> 16) & 0xffu, r3 = h >> 24;
                             r1 = r1 > r0 ? r1 : r0;
@@ -1461,10 +1467,12 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             uint8_t bytes[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++) bytes[j] = gout[has[j] ? srcs[j] : 0u];
+                            uint32_t packed = (uint32_t)bytes[0] | ((uint32_t)bytes[1] << 8) | ((uint32_t)bytes[2] << 16) | ((uint32_t)bytes[3] << 24);
+                            asm volatile("" : "+v"(packed));  // (keeps the compiler from storing the loaded bytes one by one after all)
 #pragma unroll
                             for (int j = 0; j < 4; j++)
-                                if (has[j]) gout[dsts[j]] = bytes[j];
-                            WSYNC();
+                                if (has[j]) gout[dsts[j]] = (uint8_t)(packed >> (8 * j));
+                            LSYNC();
                             mm &= ~inc;
                         }
                     }
