@@ -766,9 +766,18 @@ __device__ uint32_t wave_xxh64_low32(uint64_t *stage, const uint8_t *p, uint32_t
 
 // wave-cooperative forward copy of n bytes; dst and src may overlap with dst - src = period >= 1
 // (the LZ77 replicate case) or be disjoint
+// forward copy of n bytes (dst below src when they overlap): 16 bytes per lane and trip at any alignment, 1 KB per trip
+struct __attribute__((packed, aligned(1))) ZU128 {
+    uint32_t x, y, z, w;
+};
 __device__ __forceinline__ void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n)
 {
-    for (uint32_t j = lane_id(); j < n; j += 64) dst[j] = src[j];
+    const uint32_t lane = lane_id(), whole = n & ~15u;
+    for (uint32_t j = 16u * lane; j < whole; j += 1024u) {
+        const ZU128 v = *(const ZU128 *)(src + j);
+        *(ZU128 *)(dst + j) = v;
+    }
+    if (whole + lane < n) dst[whole + lane] = src[whole + lane];
 }
 
 __device__ void wave_match_copy(uint8_t *dst, uint32_t offset, uint32_t n)
