@@ -108,7 +108,9 @@ struct EncArgs {
 template <class LDS>
 __device__ uint32_t flush_bits(LDS &L, uint8_t *gout, uint32_t cap, uint32_t obytes, uint32_t &nbits, bool all)
 {
-    WSYNC();
+    // (LSYNC, not WSYNC: only LDS is handed between lanes here; a full fence would wait for the candidate loads of the
+    // next chunk and for the stores just issued)
+    LSYNC();
     const uint32_t lane = lane_id();
     uint32_t nbytes = all ? (nbits + 7u) >> 3 : (nbits >> 5) << 2;  // whole dwords unless closing
     const uint8_t *src = (const uint8_t *)L.obuf;
@@ -128,13 +130,13 @@ __device__ uint32_t flush_bits(LDS &L, uint8_t *gout, uint32_t cap, uint32_t oby
     }
     for (uint32_t j = 4u * ndw + lane; j < nbytes; j += 64)
         if (obytes + j < cap) gout[obytes + j] = src[j];
-    WSYNC();
+    LSYNC();
     // keep the partial dword, clear the rest
     uint32_t keep_w = nbytes >> 2;
     uint32_t carry = (!all && keep_w < LDS::OBUF) ? L.obuf[keep_w] : 0u;
-    WSYNC();
+    LSYNC();
     for (uint32_t j = lane; j < LDS::OBUF; j += 64) L.obuf[j] = j == 0 ? carry : 0u;
-    WSYNC();
+    LSYNC();
     nbits = all ? 0u : nbits - nbytes * 8u;
     return nbytes;
 }
