@@ -313,3 +313,24 @@ def test_zlib_options_surface_strategy_mem_level_default_level(gpu, alice):
 
     for bad in (_EncoderOpts(31, 1, -1, 5, 8), _EncoderOpts(31, 1, -1, 0, 10), _EncoderOpts(31, 10, -1, 0, 8), _EncoderOpts(31, -2, -1, 0, 8), _EncoderOpts(47, 1, -1, 0, 8)):
         assert not L.chip_encoder_new(C.byref(bad))
+
+
+def test_committed_encoder_digests(gpu):
+    """The kernels reproduce tests/golden/encoder_digests.json (what oracle_deflate.c's algorithm gives for the reference's
+    two fixtures, tools/make_encoder_digests.py): the pair oracle + kernels cannot drift together unnoticed."""
+    import hashlib
+    import json
+
+    import compu_amd as c
+    from conftest import GOLDEN
+
+    want = json.load(open(os.path.join(GOLDEN, "encoder_digests.json")))
+    for key, w in want.items():
+        name, mode, level, strategy = key.split(":")
+        opts = c.ZlibOptions().mode(c.ZlibMode.Gzip).compression(int(level[5:])).strategy(c.ZlibStrategy(int(strategy[8:])))
+        enc = c.encoder_interface.zlib_hip(opts)
+        vec = c.Vec()
+        r = enc.encode_vec_full(golden(name), vec, c.EncodeOp.Finish)
+        assert r.status == c.EncodeStatus.Finished
+        comp = bytes(vec)
+        assert (len(comp), hashlib.sha256(comp).hexdigest()) == (w["size"], w["sha256"]), key
