@@ -41,8 +41,12 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        # ORACLE_LIB selects another build of the same sources (`make -C oracle asan` + LD_PRELOAD of libasan: the sanitizer run)
+        path = os.environ.get("ORACLE_LIB")
+        if not path:
+            build()
+            path = _LIB_PATH
+        L = C.CDLL(path)
         u8p = C.c_void_p
         L.orc_inflate_new.restype = C.c_void_p
         L.orc_inflate_new.argtypes = [C.c_int]
