@@ -1221,8 +1221,83 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     const int32_t T0 = (int32_t)s.lo + s.avail, Tmin = (int32_t)s.lo;
                     int32_t T = T0;
                     uint32_t my_al = 0, my_ao = 0, my_am = 0;
+#ifndef CHIP_ZSTD_NO_ASM_CHAIN
+                    // (the hand-written loop addresses the tables by their offsets in ZLds: L is the kernel's only LDS object, at 0)
+                    const bool asm_chain = rdfirst((uint32_t)(uintptr_t)(__attribute__((address_space(3))) ZLds *)&L) == 0u;
+#endif
                     __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
-                    for (uint32_t j = 0; j < n_upd; j++) {
+                    uint32_t j = 0;
+                    while (rdfirst(j) < n_upd) {
+#ifndef CHIP_ZSTD_NO_ASM_CHAIN
+                        if (asm_chain) {
+                            // The loop below, written by hand: everything stays in vector registers (the values are the same in
+                            // every lane), so the dependent path of a sequence is LDS round trip -> v_add3 -> v_bfe -> v_sub ->
+                            // shift -> v_bfe -> v_lshl_add -> next LDS read, with no detour over the scalar unit.  It leaves
+                            // with code 1 at a sequence whose bits do not fit one 64-bit view (done by the C++ body below), and does
+                            // not look for the end of the stream: a position below the stream's start is found by the lanes afterwards.
+                            uint32_t tp = (uint32_t)(T - 64 - 32 * s.win0), code;
+                            const uint32_t n_upd_s = rdfirst(n_upd);
+                            uint32_t ta, td0, td1, td2, tel, teo, tem, tS, ttot, thi, tlo, tx, tW, tq;
+                            asm volatile(
+                                "s_mov_b32 %[code], 0\n\t"
+                                "1:\n\t"
+                                "v_ashrrev_i32 %[a], 5, %[tp]\n\t"
+                                "v_max_i32 %[a], 0, %[a]\n\t"
+                                "v_lshlrev_b32 %[a], 2, %[a]\n\t"
+                                "ds_read_b32 %[el], %[al] offset:%[OL]\n\t"
+                                "ds_read_b32 %[eo], %[ao] offset:%[OO]\n\t"
+                                "ds_read_b32 %[em], %[am] offset:%[OM]\n\t"
+                                "ds_read_b32 %[d0], %[a] offset:%[OW0]\n\t"
+                                "ds_read_b32 %[d1], %[a] offset:%[OW1]\n\t"
+                                "ds_read_b32 %[d2], %[a] offset:%[OW2]\n\t"
+                                "v_cmp_eq_u32 vcc, %[j], %[lane]\n\t"
+                                "v_cndmask_b32 %[myl], %[myl], %[al], vcc\n\t"
+                                "v_cndmask_b32 %[myo], %[myo], %[ao], vcc\n\t"
+                                "v_cndmask_b32 %[mym], %[mym], %[am], vcc\n\t"
+                                "s_waitcnt lgkmcnt(3)\n\t"
+                                "v_add3_u32 %[S], %[el], %[eo], %[em]\n\t"
+                                "v_bfe_u32 %[tot], %[S], 5, 7\n\t"
+                                "v_cmp_lt_u32 vcc, 64, %[tot]\n\t"
+                                "s_cbranch_vccnz 3f\n\t"
+                                "v_sub_u32 %[x], 64, %[tot]\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "v_alignbit_b32 %[hi], %[d2], %[d1], %[tp]\n\t"
+                                "v_alignbit_b32 %[lo], %[d1], %[d0], %[tp]\n\t"
+                                "v_alignbit_b32 %[lo], %[hi], %[lo], %[x]\n\t"
+                                "v_lshrrev_b32 %[hi], %[x], %[hi]\n\t"
+                                "v_cmp_gt_u32 vcc, 32, %[x]\n\t"
+                                "v_cndmask_b32 %[W], %[hi], %[lo], vcc\n\t"
+                                "v_add_u32 %[q], %[eo], %[em]\n\t"
+                                "v_bfe_u32 %[q], %[W], %[q], %[el]\n\t"
+                                "v_lshrrev_b32 %[S], 21, %[el]\n\t"
+                                "v_lshl_add_u32 %[al], %[q], 2, %[S]\n\t"
+                                "v_bfe_u32 %[q], %[W], %[eo], %[em]\n\t"
+                                "v_lshrrev_b32 %[S], 21, %[em]\n\t"
+                                "v_lshl_add_u32 %[am], %[q], 2, %[S]\n\t"
+                                "v_bfe_u32 %[q], %[W], 0, %[eo]\n\t"
+                                "v_lshrrev_b32 %[S], 21, %[eo]\n\t"
+                                "v_lshl_add_u32 %[ao], %[q], 2, %[S]\n\t"
+                                "v_sub_u32 %[tp], %[tp], %[tot]\n\t"
+                                "s_add_u32 %[j], %[j], 1\n\t"
+                                "s_cmp_lt_u32 %[j], %[n]\n\t"
+                                "s_cbranch_scc1 1b\n\t"
+                                "s_branch 5f\n\t"
+                                "3:\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "s_mov_b32 %[code], 1\n\t"
+                                "5:"
+                                : [al] "+v"(al), [ao] "+v"(ao), [am] "+v"(am), [myl] "+v"(my_al), [myo] "+v"(my_ao), [mym] "+v"(my_am), [tp] "+v"(tp),
+                                  [j] "+s"(j), [code] "=&s"(code), [a] "=&v"(ta), [d0] "=&v"(td0), [d1] "=&v"(td1), [d2] "=&v"(td2), [el] "=&v"(tel),
+                                  [eo] "=&v"(teo), [em] "=&v"(tem), [S] "=&v"(tS), [tot] "=&v"(ttot), [hi] "=&v"(thi), [lo] "=&v"(tlo), [x] "=&v"(tx),
+                                  [W] "=&v"(tW), [q] "=&v"(tq)
+                                : [n] "s"(n_upd_s), [lane] "v"(lane), [OL] "n"(offsetof(ZLds, ll)), [OO] "n"(offsetof(ZLds, of)),
+                                  [OM] "n"(offsetof(ZLds, ml)), [OW0] "n"(offsetof(ZLds, seqwin)), [OW1] "n"(offsetof(ZLds, seqwin) + 4),
+                                  [OW2] "n"(offsetof(ZLds, seqwin) + 8)
+                                : "vcc", "scc", "memory");
+                            T = (int32_t)tp + 64 + 32 * s.win0;
+                            if (code == 0) break;
+                        }
+#endif
                         int32_t wi = ((T - 64) >> 5) - s.win0;
                         wi = wi < 0 ? 0 : wi;
                         const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
@@ -1256,6 +1331,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             dec_bad = j;
                             break;
                         }
+                        j++;
                     }
                     if (dec_bad == 64 && n_upd < cn) {  // the block's last sequence: extras only, no state update
                         const uint32_t S = *(const uint32_t *)((const char *)L.ll.e + al) + *(const uint32_t *)((const char *)L.of.e + ao) +
@@ -1275,9 +1351,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     // the bits consumed, cuts the extra bits from the window and forms the values
                     uint32_t ov = 4;
                     {
-                        const bool mine = lane < cn && lane < dec_bad;
+                        const bool have = lane < cn && lane < dec_bad;
                         uint32_t my_el = 0, my_eo = 0, my_em = 0, my_tot = 0;
-                        if (mine) {
+                        if (have) {
                             my_el = *(const uint32_t *)((const char *)L.ll.e + my_al);
                             my_eo = *(const uint32_t *)((const char *)L.of.e + my_ao);
                             my_em = *(const uint32_t *)((const char *)L.ml.e + my_am);
@@ -1285,7 +1361,15 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             my_tot = (S >> 5) & 127u;
                             if (i0 + lane + 1 == nseq) my_tot -= S & 31u;
                         }
-                        const int32_t my_top = T0 - (int32_t)(wave_incl_scan(my_tot) - my_tot);
+                        const uint32_t tot_incl = wave_incl_scan(my_tot);
+                        const int32_t my_top = T0 - (int32_t)(tot_incl - my_tot);
+                        // the first sequence that reads below the stream's start is the corrupt one (the chain itself ran on)
+                        const uint64_t overm = __ballot(have && T0 - (int32_t)tot_incl < Tmin);
+                        if (overm) {
+                            const uint32_t fo = (uint32_t)__ffsll((long long)overm) - 1u;
+                            dec_bad = fo < dec_bad ? fo : dec_bad;
+                        }
+                        const bool mine = have && lane < dec_bad;
                         if (mine) {
                             const uint32_t oc = (my_eo >> 12) & 63u, mc = (my_em >> 12) & 63u, lc = (my_el >> 12) & 63u;
                             const uint32_t xl = ((my_el >> 5) & 127u) - (my_el & 31u), xm = ((my_em >> 5) & 127u) - (my_em & 31u);
