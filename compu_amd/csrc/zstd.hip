@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t my_al = 0, my_ao = 0, my_am = 0;
 #ifndef CHIP_ZSTD_NO_ASM_CHAIN
                     // (the hand-written loop addresses the tables by their offsets in ZLds: L is the kernel's only LDS object, at 0)
-                    const bool asm_chain = rdfirst((uint32_t)(uintptr_t)(__attribute__((address_space(3))) ZLds *)&L) == 0u;
+                    bool asm_chain = rdfirst((uint32_t)(uintptr_t)(__attribute__((address_space(3))) ZLds *)&L) == 0u;
 #endif
                     __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
                     uint32_t j = 0;
@@ -1232,70 +1232,91 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         if (asm_chain) {
                             // The loop below, written by hand: everything stays in vector registers (the values are the same in
                             // every lane), so the dependent path of a sequence is LDS round trip -> v_add3 -> v_bfe -> v_sub ->
-                            // shift -> v_bfe -> v_lshl_add -> next LDS read, with no detour over the scalar unit.  It leaves
-                            // with code 1 at a sequence whose bits do not fit one 64-bit view (done by the C++ body below), and does
-                            // not look for the end of the stream: a position below the stream's start is found by the lanes afterwards.
-                            uint32_t tp = (uint32_t)(T - 64 - 32 * s.win0), code;
+                            // shift -> v_bfe -> v_lshl_add -> next LDS read, with no detour over the scalar unit.  Every
+                            // state is followed at once by the read of its entry, the window words of the next sequence are requested
+                            // as soon as its bit position is known.  The loop has no data-dependent exit: a sequence whose bits do not
+                            // fit one 64-bit view (seen afterwards in the maximum of the bit counts) sends the whole chunk to the C++
+                            // loop below, and a position below the stream's start is found by the lanes in the parallel part.
+                            uint32_t tp = (uint32_t)(T - 64 - 32 * s.win0), mx = 0;
                             const uint32_t n_upd_s = rdfirst(n_upd);
+                            const uint32_t al0 = al, ao0 = ao, am0 = am, j0 = j;
                             uint32_t ta, td0, td1, td2, tel, teo, tem, tS, ttot, thi, tlo, tx, tW, tq;
                             asm volatile(
-                                "s_mov_b32 %[code], 0\n\t"
-                                "1:\n\t"
+                                // reads of the first sequence
                                 "v_ashrrev_i32 %[a], 5, %[tp]\n\t"
                                 "v_max_i32 %[a], 0, %[a]\n\t"
                                 "v_lshlrev_b32 %[a], 2, %[a]\n\t"
-                                "ds_read_b32 %[el], %[al] offset:%[OL]\n\t"
-                                "ds_read_b32 %[eo], %[ao] offset:%[OO]\n\t"
-                                "ds_read_b32 %[em], %[am] offset:%[OM]\n\t"
                                 "ds_read_b32 %[d0], %[a] offset:%[OW0]\n\t"
                                 "ds_read_b32 %[d1], %[a] offset:%[OW1]\n\t"
                                 "ds_read_b32 %[d2], %[a] offset:%[OW2]\n\t"
+                                "ds_read_b32 %[el], %[al] offset:%[OL]\n\t"
+                                "ds_read_b32 %[em], %[am] offset:%[OM]\n\t"
+                                "ds_read_b32 %[eo], %[ao] offset:%[OO]\n\t"
+                                "1:\n\t"
                                 "v_cmp_eq_u32 vcc, %[j], %[lane]\n\t"
                                 "v_cndmask_b32 %[myl], %[myl], %[al], vcc\n\t"
                                 "v_cndmask_b32 %[myo], %[myo], %[ao], vcc\n\t"
                                 "v_cndmask_b32 %[mym], %[mym], %[am], vcc\n\t"
-                                "s_waitcnt lgkmcnt(3)\n\t"
+                                "s_waitcnt lgkmcnt(0)\n\t"
                                 "v_add3_u32 %[S], %[el], %[eo], %[em]\n\t"
                                 "v_bfe_u32 %[tot], %[S], 5, 7\n\t"
-                                "v_cmp_lt_u32 vcc, 64, %[tot]\n\t"
-                                "s_cbranch_vccnz 3f\n\t"
                                 "v_sub_u32 %[x], 64, %[tot]\n\t"
-                                "s_waitcnt lgkmcnt(0)\n\t"
                                 "v_alignbit_b32 %[hi], %[d2], %[d1], %[tp]\n\t"
                                 "v_alignbit_b32 %[lo], %[d1], %[d0], %[tp]\n\t"
                                 "v_alignbit_b32 %[lo], %[hi], %[lo], %[x]\n\t"
                                 "v_lshrrev_b32 %[hi], %[x], %[hi]\n\t"
                                 "v_cmp_gt_u32 vcc, 32, %[x]\n\t"
                                 "v_cndmask_b32 %[W], %[hi], %[lo], vcc\n\t"
+                                // the next states, each followed at once by the read of its entry
                                 "v_add_u32 %[q], %[eo], %[em]\n\t"
                                 "v_bfe_u32 %[q], %[W], %[q], %[el]\n\t"
                                 "v_lshrrev_b32 %[S], 21, %[el]\n\t"
                                 "v_lshl_add_u32 %[al], %[q], 2, %[S]\n\t"
+                                "ds_read_b32 %[el], %[al] offset:%[OL]\n\t"
                                 "v_bfe_u32 %[q], %[W], %[eo], %[em]\n\t"
                                 "v_lshrrev_b32 %[S], 21, %[em]\n\t"
                                 "v_lshl_add_u32 %[am], %[q], 2, %[S]\n\t"
+                                "ds_read_b32 %[em], %[am] offset:%[OM]\n\t"
                                 "v_bfe_u32 %[q], %[W], 0, %[eo]\n\t"
                                 "v_lshrrev_b32 %[S], 21, %[eo]\n\t"
                                 "v_lshl_add_u32 %[ao], %[q], 2, %[S]\n\t"
+                                "ds_read_b32 %[eo], %[ao] offset:%[OO]\n\t"
+                                // the bit position and the window words of the next sequence
+                                "v_max_u32 %[mx], %[mx], %[tot]\n\t"
                                 "v_sub_u32 %[tp], %[tp], %[tot]\n\t"
+                                "v_ashrrev_i32 %[a], 5, %[tp]\n\t"
+                                "v_max_i32 %[a], 0, %[a]\n\t"
+                                "v_lshlrev_b32 %[a], 2, %[a]\n\t"
+                                "ds_read_b32 %[d0], %[a] offset:%[OW0]\n\t"
+                                "ds_read_b32 %[d1], %[a] offset:%[OW1]\n\t"
+                                "ds_read_b32 %[d2], %[a] offset:%[OW2]\n\t"
                                 "s_add_u32 %[j], %[j], 1\n\t"
                                 "s_cmp_lt_u32 %[j], %[n]\n\t"
                                 "s_cbranch_scc1 1b\n\t"
-                                "s_branch 5f\n\t"
-                                "3:\n\t"
-                                "s_waitcnt lgkmcnt(0)\n\t"
-                                "s_mov_b32 %[code], 1\n\t"
-                                "5:"
+                                "s_waitcnt lgkmcnt(0)"
                                 : [al] "+v"(al), [ao] "+v"(ao), [am] "+v"(am), [myl] "+v"(my_al), [myo] "+v"(my_ao), [mym] "+v"(my_am), [tp] "+v"(tp),
-                                  [j] "+s"(j), [code] "=&s"(code), [a] "=&v"(ta), [d0] "=&v"(td0), [d1] "=&v"(td1), [d2] "=&v"(td2), [el] "=&v"(tel),
+                                  [mx] "+v"(mx), [j] "+s"(j), [a] "=&v"(ta), [d0] "=&v"(td0), [d1] "=&v"(td1), [d2] "=&v"(td2), [el] "=&v"(tel),
                                   [eo] "=&v"(teo), [em] "=&v"(tem), [S] "=&v"(tS), [tot] "=&v"(ttot), [hi] "=&v"(thi), [lo] "=&v"(tlo), [x] "=&v"(tx),
                                   [W] "=&v"(tW), [q] "=&v"(tq)
                                 : [n] "s"(n_upd_s), [lane] "v"(lane), [OL] "n"(offsetof(ZLds, ll)), [OO] "n"(offsetof(ZLds, of)),
                                   [OM] "n"(offsetof(ZLds, ml)), [OW0] "n"(offsetof(ZLds, seqwin)), [OW1] "n"(offsetof(ZLds, seqwin) + 4),
                                   [OW2] "n"(offsetof(ZLds, seqwin) + 8)
                                 : "vcc", "scc", "memory");
-                            T = (int32_t)tp + 64 + 32 * s.win0;
-                            if (code == 0) break;
+#ifdef CHIP_EXP_FORCE_FALLBACK  // test hook: every chunk takes the way back through the C++ loop
+                            if (rdfirst(mx) > 1000u) {
+#else
+                            if (rdfirst(mx) <= 64u) {
+#endif
+                                T = (int32_t)tp + 64 + 32 * s.win0;
+                                break;
+                            }
+                            // rare: some sequence's bits did not fit one 64-bit view -- the states after it are wrong: the chunk is
+                            // done again by the loop below
+                            al = al0;
+                            ao = ao0;
+                            am = am0;
+                            j = j0;
+                            asm_chain = false;
                         }
 #endif
                         int32_t wi = ((T - 64) >> 5) - s.win0;
