@@ -342,11 +342,26 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
             const uint32_t room = hs.want > hs.done + first ? hs.want - (hs.done + first) : 0u;  // never write past the stream's literals
             const uint32_t n = cnt < room ? cnt : room;
 #ifndef CHIP_EXP_NOHUF
-            for (uint32_t i = 0; __any(i < n); i++) {
-                const uint32_t e = L.huf[huf_bits_peek(b, h2, (int32_t)hs.lo, hbits)];
-                if (i < n) {
-                    dst[i] = (uint8_t)e;
-                    huf_bits_skip(h2, e >> 8);
+            // four symbols per trip, stored as one dword (at any alignment) instead of four scattered byte stores
+            struct __attribute__((packed, aligned(1))) HU32 {
+                uint32_t v;
+            };
+            for (uint32_t i = 0; __any(i < n); i += 4) {
+                uint32_t word = 0;
+#pragma unroll
+                for (uint32_t t = 0; t < 4; t++) {
+                    const uint32_t e = L.huf[huf_bits_peek(b, h2, (int32_t)hs.lo, hbits)];
+                    if (i + t < n) {
+                        word |= (e & 0xffu) << (8 * t);
+                        huf_bits_skip(h2, e >> 8);
+                    }
+                }
+                if (i + 4 <= n) {
+                    ((HU32 *)(dst + i))->v = word;
+                } else if (i < n) {
+#pragma unroll
+                    for (uint32_t t = 0; t < 3; t++)
+                        if (i + t < n) dst[i + t] = (uint8_t)(word >> (8 * t));
                 }
             }
 #endif
