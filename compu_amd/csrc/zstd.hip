@@ -183,7 +183,10 @@ __device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { retu
 // pass then decodes exactly the owned symbols again and stores them.  Huffman codes re-synchronise within a few
 // symbols, so the 16 lanes cover ~16 x 224 bits per round with ~50 + 40 serial steps instead of ~570.
 constexpr int HS_BITS = 224;
-constexpr int HXT_BITS = 512;
+#ifndef CHIP_HXT_BITS
+#define CHIP_HXT_BITS 512
+#endif
+constexpr int HXT_BITS = CHIP_HXT_BITS;
 constexpr int HROW_WORDS = HS_BITS / 32;
 static_assert(HROW_WORDS * 64 <= 256 + 64 + 192, "boundary rows live in seqwin + xheads + xpar");
 
@@ -1069,7 +1072,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     hs.done = 0;
                     hs.out = myout;
                     WSYNC();
+#ifndef CHIP_EXP_NOLIT  // (ablation: no literal decoding at all)
                     if (!huf_decode4(L, b, hs, gout)) ZFAIL(ZSTD_E_CORRUPTION);
+#endif
                     WSYNC();
                 } else if (lane < streams) {  // a single stream (small literal sections): one lane, symbol by symbol
                     uint32_t myoff = st0, myout = lit_out;
