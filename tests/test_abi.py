@@ -30,6 +30,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.chip_encode_bound(31, 65536) >= 65536 + 18
 
 
+def test_encode_bound_covers_what_the_oracle_encoder_writes():
+    """chip_encode_bound is the capacity that is always enough: worst cases of every level (incompressible input: stored
+    blocks at level 0 / 1, a stored block per 65 472 tokens at the dynamic levels) through the oracle encoder."""
+    import compu_amd
+    from oracle import oracle as O
+
+    lib = compu_amd.lib()
+    rnd = os.urandom(400000)
+    for mode in (O.MODE_DEFLATE, O.MODE_ZLIB, O.MODE_GZIP):
+        for n in (0, 1, 63, 64, 65471, 65472, 65473, 65535, 65536, 131071, 200000, 400000):
+            for level in (0, 1, 3, 6):
+                e = O.DeflateEncoder(mode, level, 0)
+                comp, ir, orr, st = e.encode(rnd[:n], n + 4096, O.OP_FINISH)
+                assert st == O.ENC_FINISHED and len(comp) <= lib.chip_encode_bound(mode, n), (mode, n, level, len(comp))
+
+
 def test_detection_table_matches_reference():
     """src/decoder/mod.rs:28-114 incl. the None cases (:97-104) and the 0x68 quirk (:80-82)"""
     import compu_amd
