@@ -268,7 +268,10 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const uint32_t rr = active ? r : r0;
-                const uint32_t seg = rr / HS_BITS, off = rr - seg * HS_BITS;
+                // rr / HS_BITS by a 24-bit multiply (full rate; exact for rr < 5461: HS_MAGIC * HS_BITS - 2^20 = 192)
+                constexpr uint32_t HS_MAGIC = ((1u << 20) + HS_BITS - 1) / HS_BITS;
+                static_assert(HS_MAGIC * HS_BITS - (1u << 20) < (1u << 20) / (16u * HS_BITS + HXT_BITS), "segment index by multiplication");
+                const uint32_t seg = __umul24(rr, HS_MAGIC) >> 20, off = rr - __umul24(seg, (uint32_t)HS_BITS);
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&rows[(off >> 5) * 64 + g0 + seg], (active && seg == k) ? bit : 0u);
                 const bool joined = active && seg != k && (old & bit);
