@@ -5,16 +5,18 @@
 // dynamic-Huffman table build, bitstream decode, LZ77 copy (RFC 1951), and the zlib / gzip
 // wrappers with Adler-32 / CRC-32 verification (RFC 1950 / 1952).
 //
-// Data flow per wave:  compressed bytes --(coalesced dword loads)--> LDS input window
-//   --> canonical-Huffman LUTs in LDS --> 64 lanes decode 64 segments of the bitstream at once, each
-//   from a guessed start, recording tokens (literal | len,dist) in the wave's scratch rows (HBM/L2)
-//   and joining the lane whose segment they run into --> the chain of joins from lane 0 is the true
-//   token stream --> executed a chunk (<= 1.5 KB of output) at a time: token output offsets by wave
-//   prefix sum, the owner of every output byte by bitmap popcount, four bytes per lane per step,
-//   assembled in LDS and stored coalesced into the unit's output range in HBM (the LZ77 window is
-//   the output itself).
-// The grid is persistent: waves take units from a counter, so the token scratch is one slot per
-// resident wave, not per unit.
+// Data flow per wave:  compressed bytes --(coalesced dword loads)--> a ring of the input in LDS
+//   --> canonical-Huffman tables in LDS --> the ROLLING WALK: the block's bits are cut into a fixed grid of
+//   256-bit segments; a lane takes the next unclaimed segment, decodes the token chain that starts at its
+//   (guessed) first bit, marks the token boundaries it passes inside its own segment, keeps going past
+//   the segment's end until it steps on a boundary marked by the owner of the segment it is in (from there
+//   on the two chains are the same) and then takes the next segment.  Tokens (literal | length, distance)
+//   go to the lane's row of the wave's scratch in HBM/L2 --> when the block (or the scratch) is exhausted the
+//   chain of joins from the block's first bit is followed: that is the true token stream --> it is executed a
+//   chunk (<= 2.5 KB of output) at a time: token output offsets by wave prefix sum, literals and queued
+//   matches assembled in LDS and stored coalesced into the unit's output range in HBM (the LZ77 window is the
+//   output itself).
+// The grid is persistent: waves take units from a counter, so the token scratch is one slot per resident wave.
 #include <cstddef>
 #include <map>
 #include <mutex>
@@ -25,10 +27,22 @@
 
 namespace chip {
 
-// phases of a unit's work; experiments: -DCHIP_PHASE_FN='__attribute__((noinline))' (slower: LDS accesses through a
-// WaveLds reference become flat accesses in an out-of-line function)
+// pointers into HBM keep their address space through the scalar round trip of rdfirst_ptr (else every access through them is a
+// flat one: slower, and counted as an LDS access too)
+#define GAS __attribute__((address_space(1)))
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_u __attribute__((aligned(1)));  // at any byte address (gfx950 takes any alignment for global and LDS accesses)
+template <typename T>
+__device__ __forceinline__ GAS T *rdfirst_gptr(T *p)
+{
+    return (GAS T *)rdfirst_ptr(p);
+}
+
+// phases of a unit's work: always inlined into the kernel (LDS accesses through a WaveLds reference become flat accesses in an
+// out-of-line function: measured 25 % slower in round 2)
 #ifndef CHIP_PHASE_FN
-#define CHIP_PHASE_FN
+#define CHIP_PHASE_FN __attribute__((always_inline))
 #endif
 
 // Diagnostic build (-DCHIP_STATS): per-unit cycle and event counters; compiled out of the product.
@@ -37,7 +51,6 @@ namespace chip {
 #define STAT_T0() (st_t0_ = __builtin_readcyclecounter())
 #define STAT_ACC(i) do { unsigned long long n_ = __builtin_readcyclecounter(); st_[i] += n_ - st_t0_; st_t0_ = n_; } while (0)
 #define STAT_ADD(i, v) (st_[i] += (unsigned long long)(v))
-struct Stats { unsigned long long *st_; unsigned long long &st_t0_; };
 #define STAT_PARAM , unsigned long long *st_, unsigned long long &st_t0_
 #define STAT_ARG , st_, st_t0_
 #else
@@ -48,72 +61,92 @@ struct Stats { unsigned long long *st_; unsigned long long &st_t0_; };
 #define STAT_PARAM
 #define STAT_ARG
 #endif
-// stat slots (cycles): 0 other header work, 1 window load, 2 walk, 3 path resolve, 4 code lengths (+ block header), 5 table
-// build, 6 checksum/trailer, 7 sub-tables, 16 token groups (fetch, placement, literals, match queue), 17 match rounds,
-// 18 chunk store, 20 rest of the flush; (counts): 8 super-rounds, 9 lanes on the path, 10 tokens, 11 walk loop trips
-// (4 tokens each), 12 parallel copy passes, 13 chunks, 14 match rounds, 15 matches copied by the whole wave
+// stat slots (cycles): 0 other header work, 1 walk set-up (first window chunks), 2 walk, 3 path resolve, 4 code lengths (+ block
+// header), 5 table build, 6 checksum/trailer, 7 flush preparation (piece entry ranks), 16 token groups (fetch, placement,
+// literals, match queue), 17 match rounds, 18 chunk store, 20 rest of the flush; (counts): 8 walk rounds (macro-rounds), 9 pieces
+// on the path, 10 tokens, 11 walk trips (8 tokens each), 12 parallel copy passes, 13 chunks, 14 match rounds, 15 matches
+// copied by the whole wave, 19 pieces claimed, 21 lane-tokens decoded by the walk
 
-// ---- table entry format (shared by lit/len, distance and code-length tables) -------------------
-// [3:0] code length (0 = longer than the root table, resolve canonically)
-// [7:4] number of extra bits, [9:8] kind, [31:16] base value
+// ---- code-length alphabet: table entry format of round 1 (one level, 7-bit root) --------------------
+// [3:0] code length, [31:16] symbol
 enum : uint32_t { K_LIT = 0, K_LEN = 1, K_EOB = 2, K_BAD = 3 };
 __device__ __forceinline__ constexpr uint32_t mk_entry(uint32_t cl, uint32_t eb, uint32_t kind, uint32_t base)
 {
     return cl | (eb << 4) | (kind << 8) | (base << 16);
 }
-enum : int { T_CODES = 0, T_LENS = 1, T_DISTS = 2 };
 
-#ifndef CHIP_LIT_ROOT
-#define CHIP_LIT_ROOT 9   // 9/8-bit roots: 3 KB of tables; longer codes take the canonical register path
-#define CHIP_DIST_ROOT 8
-#endif
-constexpr int LIT_ROOT = CHIP_LIT_ROOT;
-constexpr int DIST_ROOT = CHIP_DIST_ROOT;
+constexpr int LIT_ROOT = 9;
+constexpr int DIST_ROOT = 8;
 constexpr int CL_ROOT = 7;
-// Speculative wave-parallel decode geometry: per super-round lane i walks the token chain that starts at
-// B + i*S_BITS (a guess, except for lane 0) and keeps walking past its own S_BITS segment until it steps
-// on a token boundary of the lane that owns the segment it is in (from there on the two chains are the
-// same), at most XT_BITS further.  Every lane records up to ROW_TOKENS tokens.  S_BITS is an odd number
-// of dwords so that the 64 lanes' window reads hit distinct LDS banks.
-#ifndef CHIP_S_BITS  // geometry overridable for experiments
-#define CHIP_S_BITS 288
-#define CHIP_XT_BITS 1024
-#define CHIP_XT_BITS_FIXED 2048  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
-#define CHIP_ROW_TOKENS 192
-#endif
-constexpr int S_BITS = CHIP_S_BITS;
-constexpr int XT_BITS = CHIP_XT_BITS;
-#ifndef CHIP_XT_BITS_FIXED
-#define CHIP_XT_BITS_FIXED CHIP_XT_BITS
-#endif
-constexpr int XT_BITS_FIXED = CHIP_XT_BITS_FIXED;
-constexpr int ROW_TOKENS = CHIP_ROW_TOKENS;
-static_assert(S_BITS % 32 == 0 && (S_BITS / 32) % 2 == 1 && ROW_TOKENS % 4 == 0 && 64 * ROW_TOKENS < 65536, "geometry");
-constexpr int ROW_WORDS = S_BITS / 32;  // boundary bitmap words per lane (own segment only)
-// x / S_BITS for x < 2^15 (bit offsets inside a super-round) as a multiply and a shift
-constexpr uint32_t SEG_SHIFT = 22;
-constexpr uint32_t SEG_MAGIC = ((1u << SEG_SHIFT) + S_BITS - 1) / S_BITS;
-constexpr bool seg_magic_ok()
+
+// ---- literal/length and distance tables ------------------------------------------------------------
+// Literal/length codes are always looked up in two steps, without a branch (with a 9-bit root 11 % of this
+// workload's tokens have longer codes, so among 64 lanes the long path ran at every step anyway):
+//   lit_root[next 9 bits] (16 bits) = [4:0] number of further index bits nb, [15:5] index in pool[] of the code's
+//   entry (nb = 0) or of its prefix's sub-table (2^nb entries, indexed by the nb bits behind the root's nine);
+//   pool[] entry (32 bits, "final"): [4:0] code length cl, [9:5] number of extra bits eb, [14:10] cl + eb,
+//   [15] halt (end of block, or with [25]: invalid code), [24:16] value (literal byte, or length base 3..258),
+//   [31] length code.  The fields sit where v_bfe_u32 / v_alignbit_b32 read their 5-bit offset and width operands.
+// Distance codes: dist_root[next 8 bits] (16 bits) is the final entry for codes of up to 8 bits (99 % of matches):
+//   [3:0] code length, [7:4] number of extra bits, [9:8] mantissa (distance - 1 = mantissa << extra bits, plus the extra
+//   bits' value), [10] invalid code, [11] longer code: then [3:0] is the number of further index bits and
+//   {[15:12], [10:4]} the index (in 16-bit units) of a sub-table of such entries at the top of pool[].
+constexpr uint32_t F_HALT = 1u << 15, F_INV = 1u << 25, F_LEN = 1u << 31;
+constexpr uint32_t D_BAD = 1u << 10, D_LONG = 1u << 11;
+
+__device__ __forceinline__ uint32_t make_final(uint32_t sym, uint32_t len)
 {
-    for (uint32_t x = 0; x < 64u * S_BITS + 4096u; x++)
-        if (((x * SEG_MAGIC) >> SEG_SHIFT) != x / S_BITS) return false;
-    return true;
+    if (sym < 256) return len | (len << 10) | (sym << 16);
+    if (sym == 256) return len | (len << 10) | F_HALT;
+    if (sym >= 286) return len | (len << 10) | F_HALT | F_INV;
+    const uint32_t s = sym - 257;
+    uint32_t eb = 0, base = 3 + s;
+    if (s == 28) base = 258;
+    else if (s >= 8) {
+        eb = (s >> 2) - 1;
+        base = 3 + ((4 + (s & 3)) << eb);
+    }
+    return len | (eb << 5) | ((len + eb) << 10) | (base << 16) | F_LEN;
 }
-static_assert(seg_magic_ok() && (64u * S_BITS + 4096u) * (uint64_t)SEG_MAGIC < (1ull << 32) && SEG_MAGIC < (1u << 24) && 64u * S_BITS + 4096u < (1u << 24),
-              "segment index by multiplication");
-constexpr int IN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input window, dwords
-static_assert(IN_DW >= 320, "table-build scratch lives in the input window");
-constexpr size_t SCRATCH_WORDS_PER_WAVE = (size_t)64 * ROW_TOKENS;
-// Layout of a wave's token scratch: a 128-byte line holds four tokens (one 16-byte store) of each of eight neighbouring
-// lanes, so that one store instruction of the walk fills whole lines (lane l, row token k = 4q + j -> word
-// rowbase(l) + 32 q + j with rowbase(l) = (l / 8) * 8 * ROW_TOKENS + (l % 8) * 4).  With a row per lane (round 1) the 64
-// lanes of a store hit 64 different lines with 16 bytes each; doubling those stores cost +32 % kernel time.
+__device__ __forceinline__ uint32_t make_dist16(uint32_t sym, uint32_t len)
+{
+    if (sym >= 30) return len | D_BAD;
+    if (sym < 4) return len | (sym << 8);
+    return len | (((sym >> 1) - 1) << 4) | ((2 + (sym & 1)) << 8);
+}
+
+// ---- geometry of the rolling walk --------------------------------------------------------------------
+// The input bits of a walk round lie in a ring in LDS (window) next to a ring of the same shape that holds one mark bit
+// per input bit (boundaries the segments' owners have passed).  Rings are RING_CHUNKS chunks of 64 dwords (= 8 segments
+// of S_BITS = 256 bits); a chunk is loaded (and its marks cleared) once no running lane is in front of the chunk that
+// it replaces.  A round ends with the block, after PMAX segments, or when a lane's scratch row is full.
+#ifndef CHIP_RING_CHUNKS  // geometry overridable for experiments
+#define CHIP_RING_CHUNKS 12
+#endif
+constexpr uint32_t S_BITS = 256, S_SHIFT = 8;
+constexpr uint32_t RING_CHUNKS = CHIP_RING_CHUNKS;
+constexpr uint32_t RING_DW = 64 * RING_CHUNKS;
+constexpr uint32_t RING_BYTES = 4 * RING_DW;
+constexpr uint32_t PMAX = 768;         // segments (= pieces of the token stream) per walk round
+constexpr uint32_t PIECE_ITERS = PMAX / 64;
+constexpr uint32_t ROW_TOKENS = 640;   // tokens a lane can record per walk round
+constexpr uint32_t PIECE_TOKENS = 240; // tokens per piece (8-bit counts)
+constexpr uint32_t TRIP = 8;           // tokens per lane between two maintenance steps (claims, window, records)
+static_assert(PMAX % 64 == 0 && PMAX <= 1024 && ROW_TOKENS % 4 == 0 && 8u * ROW_TOKENS * 7u + 28u < 65536u && TRIP % 4 == 0, "geometry");
+constexpr uint32_t HDR_IN_DW = 192;    // input window of the block-header parser, dwords (the code lengths take <= 4584 bits)
+
+// Scratch of a wave in HBM: the lanes' token rows, then one record per piece, then the list of pieces on the true path.
+// Layout of the rows: a 128-byte line holds four tokens (one 16-byte store) of each of eight neighbouring lanes, so that one
+// store instruction of the walk fills whole lines (lane l, row token k = 4q + j -> word rowbase(l) + 32 q + j with
+// rowbase(l) = (l / 8) * 8 * ROW_TOKENS + (l % 8) * 4).
+constexpr size_t ROWS_WORDS = (size_t)64 * ROW_TOKENS;
 __device__ __forceinline__ uint32_t row_base(uint32_t l) { return (l >> 3) * (8u * ROW_TOKENS) + (l & 7u) * 4u; }
 __device__ __forceinline__ uint32_t row_word(uint32_t k) { return k + (k >> 2) * 28u; }  // 32 * (k / 4) + k % 4
 
-// token: [8:0] match length (0 = literal), [31:9] literal byte or match distance
-__device__ __forceinline__ uint32_t tok_lit(uint32_t b) { return b << 9; }
-__device__ __forceinline__ uint32_t tok_match(uint32_t len, uint32_t dist) { return len | (dist << 9); }
+// token: [8:0] literal byte, or match length 3..258; [9] match; [25:10] match distance - 1; [31:26] bits the token took in the
+// stream (the walk's flush preparation finds a piece's entry token by adding these up)
+// piece record (two words): .x = bit position the chain stopped at; .y = [5:0] lane, [15:6] first row token, [23:16] tokens, [26:24] reason
+enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
 
 struct HuffMeta {
     uint32_t limit15[16];  // [l] = end (exclusive) of the 15-bit-aligned code space of lengths <= l; [0] = 0
@@ -121,76 +154,95 @@ struct HuffMeta {
     uint32_t maxlen;
 };
 
+// LZ77 execution state of a chunk (see below)
+#ifndef CHIP_CHUNK_BYTES
+#define CHIP_CHUNK_BYTES 2560
+#endif
+#ifndef CHIP_COPY_LANE_MAX
+#define CHIP_COPY_LANE_MAX 32
+#endif
+constexpr uint32_t CHUNK_BYTES = CHIP_CHUNK_BYTES;
+constexpr uint32_t COPY_LANE_MAX = CHIP_COPY_LANE_MAX;
+constexpr uint32_t MQ_CAP = 128;  // queued matches: at most 63 left over + 64 new
+constexpr uint32_t IMG_WORDS = CHUNK_BYTES / 4 + 8;  // + room for the 16-byte reads that run past a source's end
+constexpr uint32_t TOK_RING = 4;   // token groups on their way from the scratch rows into LDS (LDS-DMA: no registers held)
+static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0 && IMG_WORDS % 2 == 0, "geometry");
+
+constexpr uint32_t PHASE_BYTES = 4 * (RING_DW + 2) + 4 * RING_DW;  // the walk's two rings are the largest phase
+constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - 32 - PHASE_BYTES) / 4;
+constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;
+
 struct alignas(16) WaveLds {
-    uint32_t lit_lut[1 << LIT_ROOT];
-    uint32_t dist_lut[1 << DIST_ROOT];
-    uint32_t lit_sorted[288];
-    uint32_t dist_sorted[32];
-    uint32_t inbuf[IN_DW];
-    union {
-        uint32_t rows[ROW_WORDS * 64];  // [word][lane]: token boundaries each lane's chain has in its own segment
-        struct {                        // block-header scratch: only live between super-rounds
+    union {  // first: the walk's window reads (ds_read2_b32) take small offsets only
+        struct {                             // walk
+            uint32_t win[RING_DW + 2];       // input dwords; two more repeat win[0..1] (a lane reads three dwords from any ring index)
+            uint32_t bm[RING_DW];            // mark bits
+        } ring;
+        struct {                             // block header and table build; sorted[] and the descriptions stay for the (slow) fallback
+            uint32_t inbuf[HDR_IN_DW];
             uint32_t cl_lut[1 << CL_ROOT];
             uint32_t cl_sorted[20];
             HuffMeta cl_h;
             uint32_t count[16];
             uint8_t lens[320];
+            uint8_t pad_[PHASE_BYTES - 4 * HDR_IN_DW - 4 * (1 << CL_ROOT) - 80 - sizeof(HuffMeta) - 64 - 320 - 2 * 288 - 2 * 32 - 2 * sizeof(HuffMeta)];
+            uint16_t lit_sorted[288];        // symbols in canonical order (behind everything the flush overlays)
+            uint16_t dist_sorted[32];
+            HuffMeta lit_h, dist_h;
         } hdr;
+        struct {                             // path resolve
+            uint16_t nxt[PMAX];
+            uint32_t on[PMAX / 32];
+        } res;
+        struct {                             // LZ77 execution
+            uint32_t out[IMG_WORDS];         // the chunk's output bytes by offset (offset 0 = the dword-aligned address below the chunk)
+            uint2 mq[MQ_CAP];                // queued match: .x offset of its first output byte, .y length | distance << 16
+            uint32_t tok[64 * TOK_RING];     // token groups, written by global_load_lds_dword
+            uint32_t pk[128];                // k-th piece of a batch: [2k] its first stream index, [2k+1] [15:0] (row token - stream index) mod 2^16, [31:16] row base
+        } fl;
+        uint32_t phase_words_[PHASE_BYTES / 4];
     };
-    uint32_t pk[128];       // k-th piece of the true stream: [2k] its first stream index, [2k+1] [15:0] (row token - stream index) mod 2^16, [31:16] row base
-    HuffMeta lit_h, dist_h;
-    uint32_t use_sub;  // long codes resolve through sub-tables living in lit_sorted/dist_sorted
+    uint16_t lit_root[1 << LIT_ROOT];
+    uint16_t dist_root[1 << DIST_ROOT];
+    uint32_t pool[POOL_WORDS];  // literal/length finals and sub-tables from the bottom, distance sub-tables (16-bit) from the top
+    uint32_t jbits[4], ebits[4];  // pieces of the last 128 claimed (bit = index mod 128): joined by another chain / ended on an end-of-block code
 };
+static_assert(sizeof(WaveLds) <= 10240, "16 waves per CU: LDS is granted in 1280-byte steps");
+static_assert(offsetof(WaveLds, hdr.lit_sorted) >= offsetof(WaveLds, fl.pk) + 512, "the fallback's tables survive the flush");
+static_assert(PMAX * 2 + PMAX / 8 <= PHASE_BYTES, "resolve state");
+// the CRC-32 tables (2048 words) take the whole structure: nothing else is live while a checksum runs
+static_assert(sizeof(WaveLds) >= 2048 * 4, "wave_crc32 needs 8 KB");
 
-// RFC 1951 sec. 3.2.5, closed forms of the base/extra tables
-__device__ __forceinline__ uint32_t make_entry(int type, uint32_t sym, uint32_t len)
+// Canonical lookup: x15 = next 15 stream bits, first bit in bit 14 (MSB-first code value).  Returns the symbol's index in
+// sorted[] (0xffffffff: no such code) and its length.
+__device__ __forceinline__ uint32_t canon_index(const HuffMeta &H, uint32_t x15, uint32_t &l)
 {
-    if (type == T_CODES) return mk_entry(len, 0, K_LIT, sym);
-    if (type == T_LENS) {
-        if (sym < 256) return mk_entry(len, 0, K_LIT, sym);
-        if (sym == 256) return mk_entry(len, 0, K_EOB, 0);
-        if (sym >= 286) return mk_entry(len, 0, K_BAD, 0);
-        uint32_t s = sym - 257;
-        if (s < 8) return mk_entry(len, 0, K_LEN, 3 + s);
-        if (s == 28) return mk_entry(len, 0, K_LEN, 258);
-        uint32_t eb = (s >> 2) - 1;
-        return mk_entry(len, eb, K_LEN, 3 + ((4 + (s & 3)) << eb));
-    }
-    if (sym >= 30) return mk_entry(len, 0, K_BAD, 0);
-    if (sym < 4) return mk_entry(len, 0, K_LEN, 1 + sym);
-    uint32_t eb = (sym >> 1) - 1;
-    return mk_entry(len, eb, K_LEN, 1 + ((2 + (sym & 1)) << eb));
-}
-
-// Canonical lookup: x15 = next 15 stream bits, first bit in bit 14 (MSB-first code value).
-__device__ __forceinline__ uint32_t canon_lookup(const HuffMeta &H, const uint32_t *sorted, uint32_t x15)
-{
-    if (x15 >= H.limit15[15]) return mk_entry(H.maxlen ? H.maxlen : 1, 0, K_BAD, 0);
-    uint32_t l = 1;
+    l = 1;
+    if (x15 >= H.limit15[15]) return 0xffffffffu;
 #pragma unroll
     for (int j = 1; j < 15; j++) l += (x15 >= H.limit15[j]) ? 1u : 0u;
-    return sorted[H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l))];
+    return H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l));
 }
 
-// Build a canonical Huffman decode table from code lengths (RFC 1951 sec. 3.2.2) with zlib's
-// acceptance rules.  Wave-cooperative; lens[] lives in LDS.  Returns 0 or -1 (uniform).
-__device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n_, int type, int root, uint32_t *lut, uint32_t *sorted,
-                           HuffMeta &H)
+// Code lengths -> canonical description H and the symbols in canonical order (RFC 1951 sec. 3.2.2), with zlib's acceptance
+// rules.  Wave-cooperative; lens[], count[] live in LDS.  Returns 0, -1 (invalid set) or 1 (empty set); uniform.
+template <typename SortedT, typename MakeT>
+__device__ __forceinline__ int canon_prep(uint32_t *count, const uint8_t *lens, int n_, bool code_lengths, SortedT *sorted, HuffMeta &H, MakeT make)
 {
     const uint32_t lane = lane_id();
     const int n = (int)rdfirst((uint32_t)n_);
-    if (lane < 16) L.hdr.count[lane] = 0;
+    if (lane < 16) count[lane] = 0;
     WSYNC();
     for (int s = lane; s < n; s += 64) {
         uint32_t l = lens[s];
-        if (l) atomicAdd(&L.hdr.count[l], 1u);
+        if (l) atomicAdd(&count[l], 1u);
     }
     WSYNC();
     uint32_t code = 0, off = 0, maxlen = 0, mynext = 0;
     int left = 1;
     bool over = false;
     for (uint32_t l = 1; l <= 15; l++) {
-        const uint32_t c = rdfirst(L.hdr.count[l]);  // every lane reads the same word: say that it is uniform
+        const uint32_t c = rdfirst(count[l]);  // every lane reads the same word: say that it is uniform
         if (c) maxlen = l;
         left = (left << 1) - (int)c;
         if (left < 0) over = true;
@@ -206,16 +258,10 @@ __device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n_
         H.offs[0] = 0;
         H.maxlen = maxlen;
     }
-    if (maxlen == 0) {
-        // empty set: zlib accepts it and every code is invalid (a code-length code made only of
-        // zeros reads as symbol 0 of length 1)
-        uint32_t e = type == T_CODES ? mk_entry(1, 0, K_LIT, 0) : mk_entry(1, 0, K_BAD, 0);
-        for (int i = lane; i < (1 << root); i += 64) lut[i] = e;
-        WSYNC();
-        return 0;
-    }
+    WSYNC();
+    if (maxlen == 0) return 1;
     if (over) return -1;
-    if (left > 0 && (type == T_CODES || maxlen != 1)) return -1;
+    if (left > 0 && (code_lengths || maxlen != 1)) return -1;
     // stable counting sort by (length, symbol)
     for (int base = 0; base < n; base += 64) {
         int s = base + (int)lane;
@@ -223,87 +269,176 @@ __device__ CHIP_PHASE_FN int build_table(WaveLds &L, const uint8_t *lens, int n_
         for (uint32_t ll = 1; ll <= maxlen; ll++) {
             uint64_t m = __ballot(l == ll);
             uint32_t bp = rdlane(mynext, ll);
-            if (l == ll) sorted[bp + __popcll(m & lanemask_lt())] = make_entry(type, (uint32_t)s, l);
+            if (l == ll) sorted[bp + __popcll(m & lanemask_lt())] = make((uint32_t)s, l);
             if (lane == ll) mynext += __popcll(m);
         }
-    }
-    WSYNC();
-    // entry-centric fill of the root table
-    for (uint32_t idx = lane; idx < (1u << root); idx += 64) {
-        uint32_t x15 = __brev(idx) >> 17;
-        uint32_t e;
-        if (x15 >= H.limit15[15]) e = mk_entry(maxlen, 0, K_BAD, 0);
-        else if (x15 >= H.limit15[root]) e = 0;
-        else e = canon_lookup(H, sorted, x15);
-        lut[idx] = e;
     }
     WSYNC();
     return 0;
 }
 
-
-// ---- second-level tables for codes longer than the root ---------------------------------------------
-// A root entry whose code is longer than ROOT carries {cl = 0, [7:4] sub-table index bits, [31:16]
-// offset}; the sub-table entry for the next `bits` stream bits holds the final entry.  Sub-tables are
-// built in scratch and then take the place of sorted[] (lit_sorted + dist_sorted = 320 entries), which
-// is dead once they exist; if a code needs more than 320 sub-entries (possible in theory, not seen) the
-// block keeps sorted[] and decodes long codes canonically instead.
-constexpr uint32_t SUB_CAP = 320;
-
-// Lay out and build the sub-tables of one alphabet into scratch[base ..]; rewrites the long root
-// entries.  Returns the number of sub-entries used, or 0xffffffff when `base + n` would exceed SUB_CAP.
-template <int ROOT>
-__device__ uint32_t build_subtables(const HuffMeta &H, const uint32_t *sorted, uint32_t *lut, uint32_t *scratch, uint32_t base)
+// The code-length alphabet's one-level table (zlib: a set made only of zeros reads as symbol 0 of length 1).
+__device__ CHIP_PHASE_FN int build_cl_table(WaveLds &L)
 {
     const uint32_t lane = lane_id();
-    const uint32_t lim_r = rdfirst(H.limit15[ROOT]), top = rdfirst(H.limit15[15]), maxlen = rdfirst(H.maxlen);
-    if (top <= lim_r) return 0;  // no code is longer than the root
-    constexpr uint32_t P = 1u << (15 - ROOT);
-    const uint32_t np = (top - lim_r + P - 1) / P;  // root prefixes that hold long codes
-    uint32_t used = 0;
-    for (uint32_t j0 = 0; j0 < np; j0 += 64) {
-        const uint32_t j = j0 + lane;
-        const bool have = j < np;
-        const uint32_t xj = lim_r + j * P;
-        uint32_t sb = 0;
-        if (have) {
-            // the longest code of a prefix is its last one (canonical order is by length)
-            uint32_t xe = xj + P < top ? xj + P - 1 : top - 1;
-            uint32_t l = 1;
-#pragma unroll
-            for (int k = 1; k < 15; k++) l += (xe >= H.limit15[k]) ? 1u : 0u;
-            sb = l - ROOT;
+    HuffMeta &H = L.hdr.cl_h;
+    const int r = canon_prep(L.hdr.count, L.hdr.lens, 19, true, L.hdr.cl_sorted, H, [](uint32_t s, uint32_t l) { return mk_entry(l, 0, K_LIT, s); });
+    if (r < 0) return -1;
+    for (uint32_t idx = lane; idx < (1u << CL_ROOT); idx += 64) {
+        uint32_t e = mk_entry(1, 0, K_LIT, 0);
+        if (r == 0) {
+            uint32_t l;
+            const uint32_t ci = canon_index(H, __brev(idx) >> 17, l);  // codes are at most 7 bits: the root covers them all
+            e = ci == 0xffffffffu ? mk_entry(H.maxlen, 0, K_BAD, 0) : L.hdr.cl_sorted[ci];
         }
-        const uint32_t size = have ? (1u << sb) : 0u;
-        const uint32_t incl = wave_incl_scan(size);
-        const uint32_t off = base + used + incl - size;
-        const uint32_t total = rdlane(incl, 63);
-        if (base + used + total > SUB_CAP) return 0xffffffffu;
-        if (have) {
-            for (uint32_t t = 0; t < size; t++) {
-                uint32_t x15 = xj + ((__brev(t) >> (32 - sb)) << (15 - ROOT - sb));
-                if (sb == 0) x15 = xj;
-                scratch[off + t] = x15 >= top ? mk_entry(maxlen, 0, K_BAD, 0) : canon_lookup(H, sorted, x15);
-            }
-            lut[__brev(xj >> (15 - ROOT)) >> (32 - ROOT)] = (sb << 4) | (off << 16);  // cl = 0: long
-        }
-        used += total;
+        L.hdr.cl_lut[idx] = e;
     }
-    return used;
+    WSYNC();
+    return 0;
 }
 
+// Literal/length tables of a block from lens[0..n).  Returns 0, -1 (invalid set), or 1: the codes' entries do not fit pool[]
+// (the caller then decodes the block with the serial fallback).  `used` = words of pool[] taken.
+__device__ CHIP_PHASE_FN int build_litlen(WaveLds &L, const uint8_t *lens, int n, uint32_t &used)
+{
+    const uint32_t lane = lane_id();
+    HuffMeta &H = L.hdr.lit_h;
+    uint16_t *const sorted = L.hdr.lit_sorted;
+    const int r = canon_prep(L.hdr.count, lens, n, false, sorted, H, [](uint32_t s, uint32_t) { return (uint16_t)s; });
+    if (r != 0) return -1;  // no literal/length code at all cannot be: the end-of-block code exists
+    const uint32_t lim_r = rdfirst(H.limit15[LIT_ROOT]), top = rdfirst(H.limit15[15]);
+    const uint32_t nshort = rdfirst(H.offs[LIT_ROOT + 1 <= 15 ? LIT_ROOT + 1 : 15]);  // symbols with codes of up to nine bits come first
+    const uint32_t nsym = rdfirst(H.offs[15]) + rdfirst(L.hdr.count[15]);
+    const uint32_t nfirst = rdfirst(H.maxlen) <= (uint32_t)LIT_ROOT ? nsym : nshort;
+    if (nfirst + 1 > POOL_WORDS) return 1;
+    for (uint32_t i = lane; i < nfirst; i += 64) {
+        const uint32_t s = sorted[i];
+        L.pool[i] = make_final(s, lens[s]);
+    }
+    const uint32_t bad_idx = nfirst;
+    const uint32_t bad_e = rdfirst(H.maxlen) | (rdfirst(H.maxlen) << 10) | F_HALT | F_INV;
+    if (lane == 0) L.pool[bad_idx] = bad_e;
+    for (uint32_t idx = lane; idx < (1u << LIT_ROOT); idx += 64) {
+        const uint32_t x15 = __brev(idx) >> 17;
+        if (x15 >= top) L.lit_root[idx] = (uint16_t)(bad_idx << 5);
+        else if (x15 < lim_r) {
+            uint32_t l;
+            L.lit_root[idx] = (uint16_t)(canon_index(H, x15, l) << 5);
+        }
+    }
+    used = nfirst + 1;
+    if (top > lim_r) {
+        // sub-tables: one per root prefix that holds longer codes; the longest code of a prefix is its last one
+        constexpr uint32_t P = 1u << (15 - LIT_ROOT);
+        const uint32_t np = (top - lim_r + P - 1) / P;
+        for (uint32_t j0 = 0; j0 < np; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < np;
+            const uint32_t xj = lim_r + j * P;
+            uint32_t sb = 0;
+            if (have) {
+                uint32_t l;
+                (void)canon_index(H, xj + P < top ? xj + P - 1 : top - 1, l);
+                sb = l - LIT_ROOT;
+            }
+            const uint32_t size = have ? (1u << sb) : 0u;
+            const uint32_t incl = wave_incl_scan(size);
+            const uint32_t off = used + incl - size;
+            const uint32_t total = rdlane(incl, 63);
+            if (used + total > POOL_WORDS) return 1;
+            if (have) {
+                for (uint32_t t = 0; t < size; t++) {
+                    const uint32_t x15 = sb ? xj + ((__brev(t) >> (32 - sb)) << (15 - LIT_ROOT - sb)) : xj;
+                    uint32_t l, e = bad_e;
+                    if (x15 < top) {
+                        const uint32_t s = sorted[canon_index(H, x15, l)];
+                        e = make_final(s, l);
+                    }
+                    L.pool[off + t] = e;
+                }
+                L.lit_root[__brev(xj >> (15 - LIT_ROOT)) >> (32 - LIT_ROOT)] = (uint16_t)((off << 5) | sb);
+            }
+            used += total;
+        }
+    }
+    WSYNC();
+    return 0;
+}
+
+// Distance tables from lens[0..n); `used` = pool words the literal/length tables took.  Returns 0, -1 or 1 as build_litlen.
+__device__ CHIP_PHASE_FN int build_dist(WaveLds &L, const uint8_t *lens, int n, uint32_t used)
+{
+    const uint32_t lane = lane_id();
+    HuffMeta &H = L.hdr.dist_h;
+    uint16_t *const sorted = L.hdr.dist_sorted;
+    const int r = canon_prep(L.hdr.count, lens, n, false, sorted, H, [](uint32_t s, uint32_t) { return (uint16_t)s; });
+    if (r < 0) return -1;
+    if (r == 1) {  // no distance code: zlib accepts the block, every match is invalid
+        for (uint32_t idx = lane; idx < (1u << DIST_ROOT); idx += 64) L.dist_root[idx] = (uint16_t)(1u | D_BAD);
+        WSYNC();
+        return 0;
+    }
+    const uint32_t lim_r = rdfirst(H.limit15[DIST_ROOT]), top = rdfirst(H.limit15[15]), maxlen = rdfirst(H.maxlen);
+    uint16_t *const pool16 = (uint16_t *)L.pool;
+    for (uint32_t idx = lane; idx < (1u << DIST_ROOT); idx += 64) {
+        const uint32_t x15 = __brev(idx) >> 17;
+        if (x15 >= top) L.dist_root[idx] = (uint16_t)(maxlen | D_BAD);
+        else if (x15 < lim_r) {
+            uint32_t l;
+            const uint32_t s = sorted[canon_index(H, x15, l)];
+            L.dist_root[idx] = (uint16_t)make_dist16(s, l);
+        }
+    }
+    if (top > lim_r) {
+        constexpr uint32_t P = 1u << (15 - DIST_ROOT);
+        const uint32_t np = (top - lim_r + P - 1) / P;  // at most 15: thirty symbols, two per longer prefix
+        uint32_t used16 = 0;
+        for (uint32_t j0 = 0; j0 < np; j0 += 64) {
+            const uint32_t j = j0 + lane;
+            const bool have = j < np;
+            const uint32_t xj = lim_r + j * P;
+            uint32_t sb = 0;
+            if (have) {
+                uint32_t l;
+                (void)canon_index(H, xj + P < top ? xj + P - 1 : top - 1, l);
+                sb = l - DIST_ROOT;
+            }
+            const uint32_t size = have ? (1u << sb) : 0u;
+            const uint32_t incl = wave_incl_scan(size);
+            const uint32_t total = rdlane(incl, 63);
+            if (2 * used + used16 + total > POOL_U16) return 1;
+            const uint32_t base16 = POOL_U16 - used16 - incl;  // sub-tables grow downwards from the top
+            if (have) {
+                for (uint32_t t = 0; t < size; t++) {
+                    const uint32_t x15 = sb ? xj + ((__brev(t) >> (32 - sb)) << (15 - DIST_ROOT - sb)) : xj;
+                    uint32_t l, e = maxlen | D_BAD;
+                    if (x15 < top) {
+                        const uint32_t s = sorted[canon_index(H, x15, l)];
+                        e = make_dist16(s, l);
+                    }
+                    pool16[base16 + t] = (uint16_t)e;
+                }
+                L.dist_root[__brev(xj >> (15 - DIST_ROOT)) >> (32 - DIST_ROOT)] = (uint16_t)(D_LONG | sb | ((base16 & 127u) << 4) | ((base16 >> 7) << 12));
+            }
+            used16 += total;
+        }
+    }
+    WSYNC();
+    return 0;
+}
 struct InWin {
     const uint32_t *g32;  // dword-aligned base covering the unit's bytes
     uint32_t total_dw;    // dwords that contain at least one byte of the unit
-    uint32_t win0;        // dword index held in inbuf[0]
+    uint32_t win0;        // header parser: dword index held in hdr.inbuf[0]
 };
+
 
 __device__ __forceinline__ void win_load(WaveLds &L, InWin &w, uint32_t dw_start)
 {
     WSYNC();
     w.win0 = dw_start;
     // all loads of the window go out before the first LDS store waits for one
-    constexpr uint32_t PER_LANE = (IN_DW + 63) / 64;
+    constexpr uint32_t PER_LANE = (HDR_IN_DW + 63) / 64;
     uint32_t v[PER_LANE];
 #pragma unroll
     for (uint32_t j = 0; j < PER_LANE; j++) {
@@ -313,7 +448,7 @@ __device__ __forceinline__ void win_load(WaveLds &L, InWin &w, uint32_t dw_start
 #pragma unroll
     for (uint32_t j = 0; j < PER_LANE; j++) {
         const uint32_t k = 64u * j + lane_id();
-        if (k < IN_DW) L.inbuf[k] = v[j];
+        if (k < HDR_IN_DW) L.hdr.inbuf[k] = v[j];
     }
     WSYNC();
 }
@@ -322,14 +457,14 @@ __device__ __forceinline__ void win_load(WaveLds &L, InWin &w, uint32_t dw_start
 __device__ __forceinline__ void win_ensure(WaveLds &L, InWin &w, uint32_t pos, uint32_t span = 64)
 {
     uint32_t d = pos >> 5;
-    if (d < w.win0 || d + ((span + 62u) >> 5) + 1u > w.win0 + IN_DW) win_load(L, w, d);
+    if (d < w.win0 || d + ((span + 62u) >> 5) + 1u > w.win0 + HDR_IN_DW) win_load(L, w, d);
 }
 
 // 64 stream bits starting at `pos` (lo = first 32)
 __device__ __forceinline__ void win_bits(const WaveLds &L, const InWin &w, uint32_t pos, uint32_t &lo, uint32_t &hi)
 {
     uint32_t D = (pos >> 5) - w.win0, sh = pos & 31;
-    uint32_t d0 = L.inbuf[D], d1 = L.inbuf[D + 1], d2 = L.inbuf[D + 2];
+    uint32_t d0 = L.hdr.inbuf[D], d1 = L.hdr.inbuf[D + 1], d2 = L.hdr.inbuf[D + 2];
     lo = __builtin_amdgcn_alignbit(d1, d0, sh);
     hi = __builtin_amdgcn_alignbit(d2, d1, sh);
 }
@@ -345,7 +480,6 @@ __device__ __forceinline__ void win_bits_uniform(const WaveLds &L, const InWin &
 }
 
 __device__ __forceinline__ uint32_t bfe(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }
-
 
 // zlib / gzip header (RFC 1950 sec. 2.2, RFC 1952 sec. 2.3), checks in zlib's order.  Returns
 // ST_RUNNING and the header length in bytes, or the final status (need-input / error / need-dict).
@@ -460,9 +594,8 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
     uint32_t q = (uint32_t)(((float)off + 0.5f) * __builtin_amdgcn_rcpf((float)d));
     return off - q * d;
 }
-
 // ---- LZ77 execution -----------------------------------------------------------------------------
-// The true token stream of a super-round is executed a chunk at a time.  A chunk is as many tokens as
+// The true token stream of a walk round is executed a chunk at a time.  A chunk is as many tokens as
 // produce at most CHUNK_BYTES of output; the chunk's output is assembled in LDS (the image) and leaves
 // with coalesced dword stores.  Tokens are taken 64 at a time (lane = token): a wave prefix sum of the
 // output lengths places every token, literal lanes drop their byte into the image at once, match lanes
@@ -472,21 +605,6 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
 // bytes with 16-byte unaligned loads and exact-length unaligned LDS stores; what is left (sources that
 // depend on matches of the same round, self-overlapping, very long or chunk-straddling matches) is done
 // in further passes or, when few, one match at a time by the whole wave.
-#ifndef CHIP_CHUNK_BYTES
-#define CHIP_CHUNK_BYTES 2560
-#endif
-#ifndef CHIP_COPY_LANE_MAX
-#define CHIP_COPY_LANE_MAX 32
-#endif
-constexpr uint32_t CHUNK_BYTES = CHIP_CHUNK_BYTES;
-constexpr uint32_t COPY_LANE_MAX = CHIP_COPY_LANE_MAX;
-constexpr uint32_t MQ_CAP = 128;  // queued matches: at most 63 left over + 64 new
-constexpr uint32_t IMG_WORDS = CHUNK_BYTES / 4 + 8;  // + room for the 16-byte reads that run past a source's end
-constexpr uint32_t TOK_RING = 4;   // token groups on their way from the scratch rows into LDS (LDS-DMA: no registers held)
-constexpr uint32_t CHUNK_LDS_WORDS = IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING;
-static_assert(CHUNK_LDS_WORDS <= IN_DW + ROW_WORDS * 64, "the chunk state lives in the input window and the boundary rows");
-static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0, "geometry");
-
 struct ChunkLds {
     uint32_t *out;  // [IMG_WORDS] the chunk's output bytes by offset (offset 0 = the dword-aligned address below the chunk)
     uint2 *mq;      // [MQ_CAP] queued match: .x offset of its first output byte, .y length | distance << 16
@@ -495,12 +613,10 @@ struct ChunkLds {
 
 __device__ __forceinline__ ChunkLds chunk_lds(WaveLds &L)
 {
-    static_assert(offsetof(WaveLds, rows) == offsetof(WaveLds, inbuf) + sizeof(uint32_t) * IN_DW, "window and rows are contiguous");
-    static_assert((offsetof(WaveLds, inbuf) + 4 * IMG_WORDS) % 8 == 0, "queue entries are 8-byte aligned");
     ChunkLds c;
-    c.out = L.inbuf;
-    c.mq = (uint2 *)(c.out + IMG_WORDS);
-    c.tok = c.out + IMG_WORDS + 2 * MQ_CAP;
+    c.out = L.fl.out;
+    c.mq = L.fl.mq;
+    c.tok = L.fl.tok;
     return c;
 }
 
@@ -530,7 +646,7 @@ __device__ __forceinline__ void copy_one_match(lds_u8 *img, const uint8_t *base,
         // a self-overlapping match repeats its first `dist` bytes; all of them lie below x and are complete
         const int32_t s = sx + (int32_t)(dist >= len ? i : small_mod(i, dist));
         uint8_t b = 0;
-        if (s < (int32_t)mis) b = base[s];
+        if (s < (int32_t)mis) b = ((GAS const uint8_t *)base)[s];
         if (s >= (int32_t)mis) b = img[s];
         img[x + i] = b;
     }
@@ -563,8 +679,14 @@ __device__ __forceinline__ void round_issue(Round &r, const ChunkLds &C, const u
     r.glob = glob_ok && r.len != 0 && r.len <= COPY_LANE_MAX && sx + (int32_t)r.len <= (int32_t)mis;
     r.v0 = U128u{0, 0, 0, 0};
     r.v1 = U128u{0, 0, 0, 0};
-    if (r.glob) r.v0 = *(const U128u *)(base + sx);
-    if (r.glob && r.len > 16u) r.v1 = *(const U128u *)(base + sx + 16);
+    if (r.glob) {
+        const u32x4_u t = *(GAS const u32x4_u *)(base + sx);
+        r.v0 = U128u{t.x, t.y, t.z, t.w};
+    }
+    if (r.glob && r.len > 16u) {
+        const u32x4_u t = *(GAS const u32x4_u *)(base + sx + 16);
+        r.v1 = U128u{t.x, t.y, t.z, t.w};
+    }
 }
 
 __device__ __forceinline__ void round_finish(const Round &r, const ChunkLds &C, const uint8_t *base, uint32_t mis STAT_PARAM)
@@ -611,7 +733,7 @@ __device__ __forceinline__ void round_finish(const Round &r, const ChunkLds &C, 
     }
 }
 
-// Executes the ntok tokens of the true stream (npieces pieces described by L.pk) into gout at opos.
+// Executes the ntok tokens of a batch of the true stream (npieces pieces described by L.fl.pk) into gout at opos.
 // Returns false when decoding must stop (error / output full).
 __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, uint32_t ntok_, uint32_t npieces_, uint8_t *gout_, uint32_t &opos_,
                              uint32_t cap_, int32_t &status STAT_PARAM)
@@ -626,8 +748,8 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
     lds_u8 *const img = (lds_u8 *)C.out;
     if (ntok == 0) return true;
     // piece `lane`: first stream index, and what to add to a stream index to get the token's word in the scratch rows
-    const uint32_t pfirst = lane < npieces ? L.pk[2u * lane] : 0xffffffffu;
-    const uint32_t pdelta = lane < npieces ? L.pk[2u * lane + 1u] : 0u;
+    const uint32_t pfirst = lane < npieces ? L.fl.pk[2u * lane] : 0xffffffffu;
+    const uint32_t pdelta = lane < npieces ? L.fl.pk[2u * lane + 1u] : 0u;
     // Token g + lane of the stream (lanes behind the end re-read the last token: no branch around the load).  The piece a
     // token lies in = pieces that start at or before it, minus one: `before` pieces start in front of the group (kept
     // up to date by the caller), those inside it are found through a 64-bit mask of their start positions, put together
@@ -668,7 +790,7 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
                      : "memory");
         slot_w = (slot_w + 1u) & (TOK_RING - 1u);
     };
-    WSYNC();  // the walk's and the resolve's LDS reads are done (the chunk state takes their place)
+    WSYNC();  // the piece descriptions are in LDS; whatever used the chunk state's place before is done
     uint32_t c0 = 0;      // tokens executed so far
     uint32_t slot_r = 0;  // ring slot of the group at c0
 #pragma unroll
@@ -694,7 +816,12 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the load into slot_r has landed
         const uint32_t t = C.tok[64u * slot_r + lane];
         const uint32_t nvalid = ntok - c0 < 64u ? ntok - c0 : 64u;
-        const uint32_t len = t & 0x1ffu, val = t >> 9;
+        // token: [8:0] literal byte or match length, [9] match, [25:10] distance - 1
+        const uint32_t ism = (uint32_t)__builtin_amdgcn_sbfe((int)t, 9, 1);  // all ones for a match
+        const uint32_t tv = t & 0x1ffu;
+        const uint32_t len = tv & ism;
+        const uint32_t dist = __builtin_amdgcn_ubfe(t, 10, 16) + 1u;
+        const uint32_t val = (dist & ism) | (tv & ~ism);
         const uint32_t olen = lane < nvalid ? (len > 1u ? len : 1u) : 0u;
         const uint32_t incl = wave_incl_scan(olen);
         const uint32_t start = run + incl - olen;
@@ -764,11 +891,11 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
             for (uint32_t xq = 4u * lane; xq < xe; xq += 256u) {
                 const uint32_t wv = C.out[xq >> 2];
                 if (xq >= mis && xq + 4u <= xe) {
-                    *(uint32_t *)(base + xq) = wv;
+                    *(GAS uint32_t *)(base + xq) = wv;
                 } else {
 #pragma unroll
                     for (int k = 0; k < 4; k++)
-                        if (xq + k >= mis && xq + k < xe) base[xq + k] = (uint8_t)(wv >> (8 * k));
+                        if (xq + k >= mis && xq + k < xe) ((GAS uint8_t *)base)[xq + k] = (uint8_t)(wv >> (8 * k));
                 }
             }
         }
@@ -789,209 +916,536 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         fresh = true;
     }
 }
-
-// ---- per-lane token decode (lanes are at different bit positions) ---------------------------------
-
-// resolve a root entry that marks a code longer than the root table: through the sub-tables, or -- when a block's long
-// codes need more sub-table entries than there is room for (possible in theory, not seen) -- canonically from the
-// sorted symbols that then still sit where the sub-tables would (slow: the table description is read from LDS)
-template <int ROOT>
-__device__ __forceinline__ uint32_t long_entry(const WaveLds &L, bool use_sub, uint32_t e, uint32_t bits, const HuffMeta &H, const uint32_t *sorted)
+// ---- the rolling walk ----------------------------------------------------------------------------------
+// unsigned minimum over the wave
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ uint32_t dpp_or_ones(uint32_t v)
 {
-    if (use_sub) return L.lit_sorted[(e >> 16) + bfe(bits, ROOT, (e >> 4) & 15u)];
-    return canon_lookup(H, sorted, __brev(bits) >> 17);
+    return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+    uint32_t t;
+    t = dpp_or_ones<0x111>(v); v = v < t ? v : t;
+    t = dpp_or_ones<0x112>(v); v = v < t ? v : t;
+    t = dpp_or_ones<0x114>(v); v = v < t ? v : t;
+    t = dpp_or_ones<0x118>(v); v = v < t ? v : t;
+    t = dpp_or_ones<0x142, 0xa>(v); v = v < t ? v : t;
+    t = dpp_or_ones<0x143, 0xc>(v); v = v < t ? v : t;
+    return rdlane(v, 63);
 }
 
-// why a lane stopped walking
-enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
+// the wave's scratch in HBM
+struct Scratch {
+    uint32_t *rows;   // token rows
+    uint2 *rec;       // [PMAX] piece records
+    uint32_t *path;   // [PMAX] two words per non-empty piece of the true path, in stream order (the flush's piece descriptions)
+    uint32_t *marks;  // [8 * PMAX + 64] the round's mark bits (spilled from the ring as its chunks are replaced)
+};
+constexpr size_t SCRATCH_WORDS = ROWS_WORDS + 2 * PMAX + 2 * PMAX + 8 * PMAX + 64;
 
-// Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them
-// into gout as it goes.  On return `pos` is behind the end-of-block code (status stays
-// ST_RUNNING) or status holds the reason decoding stopped.
+constexpr uint32_t NONE = 0xffffffffu;
+
+// One round of the walk: decodes from the true token boundary G on, over at most PMAX segments of the grid that starts at
+// G's dword.  Tokens go to rows, a record per segment ("piece") to sc.rec, the mark bits to sc.marks.  Returns the number of
+// pieces claimed.
+__device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const uint32_t G_, const uint32_t end_bit_, const Scratch &sc STAT_PARAM)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t G = rdfirst(G_), end_bit = rdfirst(end_bit_);
+    GAS const uint32_t *const g32 = rdfirst_gptr(w.g32);
+    const uint32_t total_dw = rdfirst(w.total_dw);
+    GAS uint32_t *const myrow = rdfirst_gptr(sc.rows) + row_base(lane);
+    GAS u32x2 *const recg = (GAS u32x2 *)rdfirst_gptr(sc.rec);
+    GAS uint32_t *const marks = rdfirst_gptr(sc.marks);
+    uint16_t *const pool16 = (uint16_t *)L.pool;
+    const uint32_t D0 = G >> 5;                 // the grid's first dword: segment k = dwords D0 + 8 k .. D0 + 8 k + 7
+    const uint32_t gbit = D0 << 5;
+    uint32_t nseg_end = (end_bit - gbit + S_BITS - 1) >> S_SHIFT;  // segments that start in front of the input's end
+    nseg_end = nseg_end < PMAX ? nseg_end : PMAX;
+    // chunks (64 dwords) the round can need: its segments plus what a token that starts in the last one may read
+    uint32_t cmax = (8u * nseg_end + 11u + 63u) >> 6;
+    {
+        const uint32_t cin = ((end_bit + 31u) >> 5) - D0 + 3u;  // ... but nothing behind the input's end
+        const uint32_t c2 = (cin + 63u) >> 6;
+        cmax = cmax < c2 ? cmax : c2;
+    }
+    auto chunk_word = [&](uint32_t c) -> uint32_t {
+        const uint32_t i = D0 + 64u * c + lane;
+        return i < total_dw ? g32[i] : 0u;
+    };
+    WSYNC();  // the phase before (header parse, previous flush) is done with the rings' place
+    if (lane < 4) {
+        L.jbits[lane] = lane == 0 ? 1u : 0u;  // piece 0 starts on the true stream
+        L.ebits[lane] = 0;
+    }
+    // the first chunks: all loads go out before the first LDS store waits for one
+    uint32_t cload = cmax < RING_CHUNKS ? cmax : RING_CHUNKS;
+    {
+        uint32_t v[RING_CHUNKS];
+#pragma unroll
+        for (uint32_t c = 0; c < RING_CHUNKS; c++) v[c] = c < cload ? chunk_word(c) : 0u;
+#pragma unroll
+        for (uint32_t c = 0; c < RING_CHUNKS; c++) {
+            L.ring.win[64u * c + lane] = v[c];
+            L.ring.bm[64u * c + lane] = 0;
+        }
+        if (lane < 2) L.ring.win[RING_DW + lane] = v[0];
+    }
+    uint32_t slot = cload == RING_CHUNKS ? 0u : cload;  // ring slot of chunk cload
+    uint32_t preA = cload < cmax ? chunk_word(cload) : 0u;          // chunks cload and cload + 1 on their way: even chunk numbers in
+    uint32_t preB = cload + 1 < cmax ? chunk_word(cload + 1) : 0u;  // one register, odd ones in the other
+    if (cload & 1u) {
+        const uint32_t t = preA;
+        preA = preB;
+        preB = t;
+    }
+    LSYNC();
+    STAT_ACC(1);
+    STAT_ADD(8, 1);
+
+    // per-lane state
+    uint32_t seg = NONE, p = 0, own_end = 0, nst = 0, rowstart = 0, rowpos = 0, stop = R_RUN;
+    uint32_t pg = 0, ng = 0;           // position and count at the start of the running group of four tokens
+    uint32_t jb = 0, z = 0, pn = 0;    // of the lane's last token: join bit, halt flags, end position
+    bool stopped = false;              // the lane's last token was not taken
+    // wave state
+    uint32_t next_seg = 0, dl = 0, epoch = 0;
+    bool draining = false;
+    for (;;) {
+        // ======== maintenance: blocked lanes, finished pieces, window, claims ========
+        const uint32_t F = gbit + (next_seg << S_SHIFT);  // first bit nobody has claimed
+        bool held = seg != NONE;
+        if (stopped) {  // why the lane's last token was not taken, in zlib's order of verdicts
+            if (jb) stop = R_JOIN;
+            else if (pn > end_bit) stop = R_NEED_INPUT;  // the token does not end inside the input: the chain ends here, whatever comes
+            else if (z) stop = z == F_HALT ? (uint32_t)R_EOB : (uint32_t)R_BAD;
+            else {
+                p = pg;  // the window was not there yet: again from the group's start (a group's tokens are stored together)
+                nst = ng;
+            }
+        }
+        stopped = false;
+        if (held && stop == R_RUN) {
+            if (draining && p >= F) stop = R_LIMIT;  // nobody will mark a boundary out there any more
+            if (nst >= PIECE_TOKENS || rowstart + nst + TRIP + 4u > ROW_TOKENS) stop = R_LIMIT;
+        }
+        bool fin = held && stop != R_RUN;
+        uint64_t trig = 0;
+        if (__any(fin)) {
+            const uint32_t jseg = (p - gbit) >> S_SHIFT;
+            if (fin && stop == R_JOIN) atomicOr(&L.jbits[(jseg >> 5) & 3u], 1u << (jseg & 31u));
+            if (fin && stop == R_EOB && next_seg - seg < 128u) atomicOr(&L.ebits[(seg >> 5) & 3u], 1u << (seg & 31u));
+            LSYNC();
+            // an end-of-block code on a chain that another chain has joined (or that started the round) ends the round at once:
+            // a guess -- the path resolve below is what decides -- that keeps the walk from running on into the next block
+            bool t = false;
+            if (fin && stop == R_JOIN) t = (L.ebits[(jseg >> 5) & 3u] >> (jseg & 31u)) & 1u;
+            if (fin && stop == R_EOB && next_seg - seg < 128u) t = (L.jbits[(seg >> 5) & 3u] >> (seg & 31u)) & 1u;
+            trig = __ballot(t);
+            if (trig) {
+                if (held && stop == R_RUN) stop = R_LIMIT;
+                fin = held;
+            }
+            if (fin) {
+                recg[seg] = u32x2{p, lane | (rowstart << 6) | (nst << 16) | (stop << 24)};
+                rowpos = (rowstart + nst + 3u) & ~3u;
+                seg = NONE;
+                stop = R_RUN;
+            }
+        }
+        if (trig) break;
+        held = seg != NONE;
+        // ---- window: up to two chunks per step, each replacing the ring's oldest once no lane is in front of its end
+        {
+            dl = wave_min_u32(held ? (p >> 5) - D0 : 8u * next_seg);  // lowest dword (from D0) a lane may still touch
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                if (cload < cmax && dl >= 64u * (cload - RING_CHUNKS + 1u)) {
+                    const uint32_t v = (cload & 1u) ? preB : preA;
+                    const uint32_t old = L.ring.bm[64u * slot + lane];
+                    marks[64u * (cload - RING_CHUNKS) + lane] = old;  // the marks of the chunk that leaves the ring
+                    L.ring.win[64u * slot + lane] = v;
+                    L.ring.bm[64u * slot + lane] = 0;
+                    if (slot == 0 && lane < 2) L.ring.win[RING_DW + lane] = v;
+                    const uint32_t nx = cload + 2u < cmax ? chunk_word(cload + 2u) : 0u;
+                    if (cload & 1u) preB = nx;
+                    else preA = nx;
+                    cload++;
+                    slot = slot + 1u == RING_CHUNKS ? 0u : slot + 1u;
+                }
+            }
+            LSYNC();
+        }
+        // a token may be taken if it ends in front of `hard`: the input's end, and what the ring holds (a lane reads three
+        // dwords from its position on)
+        const uint32_t avail = ((D0 + 64u * cload) << 5) - 96u;  // (once the input's last dword is in, this lies behind end_bit)
+        const uint32_t hard = end_bit < avail ? end_bit : avail;
+        // ---- claims: idle lanes take the next segments in lane order
+        {
+            const bool want = !held && rowpos + 64u <= ROW_TOKENS;
+            if (__any(!held && !want)) draining = true;  // a full row: let the round end (the next one starts with empty rows)
+            uint32_t lim = next_seg;
+            if (!draining) {
+                lim = nseg_end;
+                if (cload < cmax) {
+                    const uint32_t lw = 8u * cload - 1u;  // segment k reads up to dword 8 k + 10
+                    lim = lim < lw ? lim : lw;
+                }
+            }
+            const uint64_t fm = __ballot(want);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+            const uint32_t k = next_seg + rank;
+            if (want && k < lim) {
+                seg = k;
+                p = k == 0 ? G : gbit + (k << S_SHIFT);
+                own_end = gbit + ((k + 1u) << S_SHIFT);
+                rowstart = rowpos;
+                nst = 0;
+                if (k != 0) {
+                    atomicAnd(&L.jbits[(k >> 5) & 3u], ~(1u << (k & 31u)));
+                    atomicAnd(&L.ebits[(k >> 5) & 3u], ~(1u << (k & 31u)));
+                }
+            }
+            const uint32_t nfree = (uint32_t)__popcll(fm), room = lim > next_seg ? lim - next_seg : 0u;
+            const uint32_t ncl = nfree < room ? nfree : room;
+            next_seg += ncl;
+            STAT_ADD(19, ncl);
+            if (next_seg >= nseg_end) draining = true;
+        }
+        bool run = seg != NONE;
+        if (!__any(run)) {
+            if (draining) break;
+            continue;  // waiting for the window (cannot last: an idle wave's chunks are always replaceable)
+        }
+        // ring address of a position: byte offset of its dword from the first dword of the oldest ring epoch a lane can be in (dl,
+        // found before the claims, is still the lowest dword in use: a claimed segment starts where dl's idle lanes put it)
+        while (dl >= epoch + RING_DW) epoch += RING_DW;
+        const uint32_t base4 = 4u * (D0 + epoch);
+        STAT_ADD(11, 1);
+        // ======== a trip: TRIP tokens per running lane ========
+        // A token's work is straight-line code; a lane whose token cannot be taken (it joined another chain, met an end-of-block or
+        // invalid code, or the token ends behind `hard`) drops out of the trip with jb / z / pn as that step left them: the next
+        // maintenance step reads the reason off them.
+        auto token = [&](uint32_t &tok) -> bool {
+            const uint32_t x = ((p >> 3) & ~3u) - base4;
+            const uint32_t xw = x - RING_BYTES;
+            const uint32_t a = x < xw ? x : xw;  // x mod RING_BYTES (x < 2 RING_BYTES)
+            const uint32_t bit = 1u << (p & 31u);
+            const uint32_t mine = p < own_end ? bit : 0u;
+            const uint32_t old = atomicOr((uint32_t *)((uint8_t *)L.ring.bm + a), mine);
+            jb = old & (bit - mine);  // a boundary of the segment's owner: from here on the two chains are one
+            const uint32_t *wp = (const uint32_t *)((const uint8_t *)L.ring.win + a);
+            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, p), hi = __builtin_amdgcn_alignbit(d2, d1, p);
+            const uint32_t r = L.lit_root[lo & ((1u << LIT_ROOT) - 1u)];
+            const uint32_t e = L.pool[(r >> 5) + __builtin_amdgcn_ubfe(lo, LIT_ROOT, r)];
+            const uint32_t n1 = __builtin_amdgcn_ubfe(e, 10, 5);
+            const uint32_t msk = (uint32_t)((int32_t)e >> 31);  // all ones for a length code
+            const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+            uint32_t m = L.dist_root[w2 & ((1u << DIST_ROOT) - 1u)] & msk;
+            if (m & D_LONG) {  // a distance code of more than 8 bits (1 % of the matches): through its sub-table
+                const uint32_t b16 = ((m >> 4) & 127u) | ((m >> 12) << 7);
+                m = pool16[b16 + __builtin_amdgcn_ubfe(w2, DIST_ROOT, m)];
+            }
+            const uint32_t cl2 = m & 15u, eb2 = __builtin_amdgcn_ubfe(m, 4, 4);
+            const uint32_t dm1 = (__builtin_amdgcn_ubfe(m, 8, 2) << eb2) + __builtin_amdgcn_ubfe(w2, cl2, eb2);
+            z = (e & (F_HALT | F_INV)) | (m & D_BAD);
+            pn = p + n1 + cl2 + eb2;
+            if ((jb | z) != 0 || pn > hard) return false;
+            const uint32_t v = __builtin_amdgcn_ubfe(lo, e, e >> 5) + __builtin_amdgcn_ubfe(e, 16, 9);
+            tok = (((dm1 << 10) | 512u) & msk) | v;
+            p = pn;
+            nst++;
+            return true;
+        };
+#pragma unroll
+        for (uint32_t gq = 0; gq < TRIP / 4; gq++) {
+            uint32_t t4[4] = {0, 0, 0, 0};
+            const bool ran = run;
+            if (run) {
+                pg = p;
+                ng = nst;
+                bool ok = token(t4[0]);
+                if (ok) {
+                    ok = token(t4[1]);
+                    if (ok) {
+                        ok = token(t4[2]);
+                        if (ok) ok = token(t4[3]);
+                    }
+                }
+                run = ok;
+            }
+            if (ran && nst > ng) *(GAS u32x4 *)(myrow + 8u * (rowstart + ng)) = u32x4{t4[0], t4[1], t4[2], t4[3]};
+            STAT_ADD(21, __popcll(__ballot(ran)));
+        }
+        stopped = seg != NONE && !run;
+    }
+    // the marks still in the ring
+    {
+        const uint32_t first = cload > RING_CHUNKS ? cload - RING_CHUNKS : 0u;
+        uint32_t s = cload > RING_CHUNKS ? slot : 0u;  // the oldest chunk's slot
+        for (uint32_t c = first; c < cload; c++) {
+            marks[64u * c + lane] = L.ring.bm[64u * s + lane];
+            s = s + 1u == RING_CHUNKS ? 0u : s + 1u;
+        }
+    }
+    return next_seg;
+}
+
+// Follows the chain of joins from piece 0 through the records of the round's P pieces and writes the flush's piece descriptions
+// (two words per non-empty piece of the true path, in stream order) to sc.path.  Returns their number; term_piece / term_why /
+// term_pos describe how the stream ends.
+__device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, const uint32_t P_, const uint32_t G_, uint32_t &ntok_out, uint32_t &term_why, uint32_t &term_pos STAT_PARAM)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t P = rdfirst(P_), G = rdfirst(G_), gbit = (G >> 5) << 5;
+    GAS const u32x2 *const recg = (GAS const u32x2 *)rdfirst_gptr(sc.rec);
+    GAS uint32_t *const pathg = rdfirst_gptr(sc.path);
+    GAS const uint32_t *const marks = rdfirst_gptr(sc.marks);
+    WSYNC();  // records, tokens and marks have landed; the rings are dead
+    uint32_t q[PIECE_ITERS], info[PIECE_ITERS], nx[PIECE_ITERS];
+    uint8_t *const entry = (uint8_t *)L.phase_words_ + sizeof(L.res);  // offset (bits) inside its segment at which the true stream enters a piece
+#pragma unroll
+    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+        const uint32_t k = 64u * i + lane;
+        u32x2 r = u32x2{0, R_LIMIT << 24};
+        if (k < P) r = recg[k];
+        q[i] = r.x - gbit;
+        info[i] = r.y;
+        nx[i] = ((r.y >> 24) & 7u) == R_JOIN ? q[i] >> S_SHIFT : k;
+        L.res.nxt[k] = (uint16_t)nx[i];
+    }
+    if (lane < PMAX / 32) L.res.on[lane] = lane == 0 ? 1u : 0u;
+    LSYNC();
+    // pieces on the path from piece 0, by pointer doubling over the join links (links only point forward)
+    const uint32_t rounds = P > 1 ? 32u - (uint32_t)__clz((int)(P - 1u)) : 0u;
+    for (uint32_t r = 0; r < rounds; r++) {
+        uint32_t nn[PIECE_ITERS];
+#pragma unroll
+        for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+            const uint32_t k = 64u * i + lane;
+            nn[i] = nx[i];
+            if (64u * i < P) {
+                const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
+                if (on && nx[i] != k) atomicOr(&L.res.on[nx[i] >> 5], 1u << (nx[i] & 31u));
+                nn[i] = L.res.nxt[nx[i]];
+            }
+        }
+        LSYNC();
+#pragma unroll
+        for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+            nx[i] = nn[i];
+            if (64u * i < P) L.res.nxt[64u * i + lane] = (uint16_t)nn[i];
+        }
+        LSYNC();
+    }
+    // where the stream enters each piece of the path: the position its predecessor joined at
+    if (lane == 0) entry[0] = (uint8_t)(G - gbit);
+    LSYNC();
+#pragma unroll
+    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+        const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
+        if (64u * i < P && on && ((info[i] >> 24) & 7u) == R_JOIN) entry[q[i] >> S_SHIFT] = (uint8_t)(q[i] & (S_BITS - 1u));
+    }
+    LSYNC();
+    // descriptions in stream order; a piece's first token on the stream = the boundaries its owner marked in front of the entry
+    uint32_t npk = 0, ntok = 0, kz = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+        if (64u * i < P) {  // uniform
+            const uint32_t k = 64u * i + lane;
+            const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
+            const uint64_t onm = __ballot(on);
+            if (onm) kz = 64u * i + 63u - (uint32_t)__clzll((long long)onm);
+            uint32_t a0 = 0;
+            if (on) {
+                const uint32_t eo = entry[k];
+                const u32x4 m0 = *(GAS const u32x4 *)(marks + 8u * k), m1 = *(GAS const u32x4 *)(marks + 8u * k + 4u);
+                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+#pragma unroll
+                for (uint32_t wd = 0; wd < 8; wd++) {
+                    const int32_t nb = (int32_t)eo - 32 * (int32_t)wd;
+                    const uint32_t msk = nb <= 0 ? 0u : nb >= 32 ? 0xffffffffu : (1u << nb) - 1u;
+                    a0 += __popc(mw[wd] & msk);
+                }
+            }
+            const uint32_t nst = (info[i] >> 16) & 255u;
+            const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
+            const uint32_t incl = wave_incl_scan(cnt);
+            const uint64_t nonempty = __ballot(cnt != 0);
+            if (cnt) {
+                const uint32_t first = ntok + incl - cnt;
+                const uint32_t slot = npk + (uint32_t)__popcll(nonempty & lanemask_lt());
+                const uint32_t rowtok = ((info[i] >> 6) & 1023u) + a0;
+                pathg[2u * slot] = first;
+                pathg[2u * slot + 1u] = ((rowtok - first) & 0xffffu) | (row_base(info[i] & 63u) << 16);
+            }
+            npk += (uint32_t)__popcll(nonempty);
+            ntok += rdlane(incl, 63u);
+        }
+    }
+    // how the stream ends: the last piece of the path
+    {
+        const uint32_t zi = kz >> 6, zl = kz & 63u;
+        uint32_t wq = 0, wi = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PIECE_ITERS; i++)
+            if (i == zi) {
+                wq = rdlane(q[i], zl);
+                wi = rdlane(info[i], zl);
+            }
+        term_why = (wi >> 24) & 7u;
+        term_pos = wq + gbit;
+    }
+    ntok_out = ntok;
+    STAT_ADD(9, npk);
+    STAT_ADD(10, ntok);
+    return npk;
+}
+// ---- a block's tokens: walk rounds, path resolve, execution --------------------------------------------
+// Serial stand-in for a walk round, for a block whose tables do not fit pool[] (more than ~600 table entries behind the 9-bit
+// root: possible in theory, not seen): up to 256 tokens, one at a time, every lane doing the same work, codes resolved
+// canonically from the sorted symbols that the table build leaves at the end of the header's LDS.  The tokens go to lane 0's
+// row as one piece.  Slow; exists so that every valid stream decodes.
+__device__ CHIP_PHASE_FN uint32_t serial_round(WaveLds &L, InWin &w, uint32_t pos, const uint32_t end_bit, const Scratch &sc, uint32_t &ntok_out,
+                                               uint32_t &term_why, uint32_t &term_pos)
+{
+    const uint32_t lane = lane_id();
+    GAS uint32_t *const row0 = rdfirst_gptr(sc.rows);  // lane 0's row (row_base(0) = 0)
+    GAS uint32_t *const pathg = rdfirst_gptr(sc.path);
+    uint32_t n = 0, why = R_LIMIT;
+    while (n < 256u) {
+        if (pos >= end_bit) {
+            why = R_NEED_INPUT;
+            break;
+        }
+        win_ensure(L, w, pos, 64);
+        uint32_t lo, hi;
+        win_bits_uniform(L, w, pos, lo, hi);
+        uint32_t l;
+        const uint32_t ci = canon_index(L.hdr.lit_h, __brev(lo) >> 17, l);
+        const uint32_t e = ci == 0xffffffffu ? (rdfirst(L.hdr.lit_h.maxlen) | F_HALT | F_INV) : make_final(L.hdr.lit_sorted[ci], l);
+        const uint32_t cl = e & 31u, eb = (e >> 5) & 31u, n1 = cl + eb;
+        uint32_t tb = n1;
+        uint32_t tok = bfe(lo, cl, eb) + bfe(e, 16, 9);
+        bool bad = (e & F_HALT) && (e & F_INV);
+        const bool eob = (e & F_HALT) && !(e & F_INV);
+        if (e & F_LEN) {
+            const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+            uint32_t l2;
+            const uint32_t di = canon_index(L.hdr.dist_h, __brev(w2) >> 17, l2);
+            const uint32_t dmax = rdfirst(L.hdr.dist_h.maxlen);
+            const uint32_t m = di == 0xffffffffu ? ((dmax ? dmax : 1u) | D_BAD) : make_dist16(L.hdr.dist_sorted[di], l2);
+            const uint32_t cl2 = m & 15u, eb2 = bfe(m, 4, 4);
+            tb += cl2 + eb2;
+            tok |= 512u | (((bfe(m, 8, 2) << eb2) + bfe(w2, cl2, eb2)) << 10);
+            bad = bad || (m & D_BAD);
+        }
+        tb = rdfirst(tb);
+        if (pos + tb > end_bit) {  // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
+            why = R_NEED_INPUT;
+            break;
+        }
+        if (rdfirst((uint32_t)eob)) {
+            why = R_EOB;
+            break;
+        }
+        if (rdfirst((uint32_t)bad)) {
+            why = R_BAD;
+            break;
+        }
+        if (lane == 0) row0[row_word(n)] = tok;
+        n++;
+        pos += tb;
+    }
+    if (lane == 0) {
+        pathg[0] = 0;
+        pathg[1] = 0;
+    }
+    ntok_out = n;
+    term_why = why;
+    term_pos = pos;
+    return n ? 1u : 0u;
+}
+
+// Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them into gout.  On return `pos` is
+// behind the end-of-block code (status stays ST_RUNNING) or status holds the reason decoding stopped.
 __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                             const uint32_t cap, int32_t &status, uint32_t *grow, const uint32_t xt_bits STAT_PARAM)
+                                           const uint32_t cap, int32_t &status, const Scratch &sc, const uint32_t eob_len, const bool serial STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     pos = rdfirst(pos);
     opos = rdfirst(opos);
-    const bool use_sub = rdfirst(L.use_sub) != 0;
-    uint32_t *const myrow = grow + row_base(lane);
+    GAS const uint32_t *const pathg = rdfirst_gptr(sc.path);
     for (;;) {
-        const uint32_t B = pos;
-        if (B >= end_bit) {
+        if (pos >= end_bit) {
             status = CHIP_NEED_INPUT;
             return;
         }
         STAT_T0();
-        win_load(L, w, B >> 5);
-#pragma unroll
-        for (int k = 0; k < ROW_WORDS; k++) L.rows[k * 64 + lane] = 0;
-        WSYNC();
-        STAT_ACC(1);
-        STAT_ADD(8, 1);
-        // ---- walk: every lane decodes from its guessed start until it joins another lane's chain ----
-        const uint32_t s = B + lane * S_BITS;
-        uint32_t lim = s + S_BITS + xt_bits;
-        if (lim > B + 64u * S_BITS) lim = B + 64u * S_BITS;  // nobody to join behind the last segment
-        // Why a lane stopped is worked out once, after the loop: a stopped lane's position no longer moves, so the straight-line
-        // decode of every later step (all lanes run it) reproduces the stopping step's entries; per step only the running
-        // state (position, token count, three lane masks) is updated.
-        uint32_t p = s, nst = 0;
-        bool active = s < end_bit;
-        bool by_limit = !active;   // stopped because its chain simply ended (or never ran): nothing to report
-        bool by_join = false;      // stopped on a boundary already marked by that segment's owner
-        uint32_t seg = lane, cl = 0, kind = K_LIT, kind2 = K_LIT, tb = 0;
-        bool islen = false;
-        while (__any(active)) {
-            STAT_ADD(11, 1);
-            uint32_t t4[4];
-            const uint32_t q0 = nst;
-            const bool was = active;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                // the boundary at p: marked in the lane's own row, looked up in the row of the segment's owner elsewhere
-                // (segment and offset inside it by a multiplication; a stopped lane keeps a harmless index)
-                const uint32_t rel = p - B;
-                // (24-bit multiplies: full rate; v_mul_lo_u32 takes four times as long.  rel and SEG_MAGIC are below 2^24)
-                seg = (__umul24(rel, SEG_MAGIC) >> SEG_SHIFT) & 63u;
-                const uint32_t off = rel - __umul24(seg, (uint32_t)S_BITS);
-                const uint32_t bit = 1u << (off & 31u);
-                const uint32_t old = atomicOr(&L.rows[(off >> 5) * 64 + seg], (active && seg == lane) ? bit : 0u);
-                const bool joined = active && seg != lane && (old & bit);
-                // straight-line token decode: the distance lookup runs for every lane (a literal lane just ignores
-                // it), which costs no extra issue slots and saves the exec-mask bookkeeping of a divergent branch
-                uint32_t lo, hi;
-                win_bits(L, w, p, lo, hi);
-                uint32_t e = L.lit_lut[lo & ((1u << LIT_ROOT) - 1)];
-                if ((e & 15u) == 0) e = long_entry<LIT_ROOT>(L, use_sub, e, lo, L.lit_h, L.lit_sorted);
-                cl = e & 15u;
-                const uint32_t eb = (e >> 4) & 15u;
-                kind = (e >> 8) & 3u;
-                const uint32_t n1 = cl + eb;
-                islen = kind == K_LEN;
-                const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-                uint32_t e2 = L.dist_lut[w2 & ((1u << DIST_ROOT) - 1)];
-                if (islen && (e2 & 15u) == 0) e2 = long_entry<DIST_ROOT>(L, use_sub, e2, w2, L.dist_h, L.dist_sorted);
-                const uint32_t cl2 = e2 & 15u, eb2 = (e2 >> 4) & 15u;
-                kind2 = (e2 >> 8) & 3u;
-                tb = n1 + (islen ? cl2 + eb2 : 0u);
-                t4[j] = islen ? tok_match((e >> 16) + bfe(lo, cl, eb), (e2 >> 16) + bfe(w2, cl2, eb2)) : tok_lit(e >> 16);
-                // end of block / invalid code (kinds 2 and 3), invalid distance code, input exhausted inside the token
-                const bool halt = kind >= K_EOB || (islen && kind2 == K_BAD) || p + tb > end_bit;
-                const bool go = active && !joined && !halt;
-                by_join = by_join || joined;
-                nst += go ? 1u : 0u;
-                p += go ? tb : 0u;
-                active = go && p < lim && nst < (uint32_t)ROW_TOKENS;
-                by_limit = by_limit || (go && !active);  // the chain simply ends here
-            }
-            if (was && nst > q0) *(uint4 *)(myrow + 8u * q0) = make_uint4(t4[0], t4[1], t4[2], t4[3]);  // q0 is a multiple of 4: row_word(q0)
+        uint32_t ntok = 0, why = 0, tpos = 0, npk;
+        if (serial) {
+            npk = serial_round(L, w, pos, end_bit, sc, ntok, why, tpos);
+        } else {
+            const uint32_t P = walk_round(L, w, pos, end_bit, sc STAT_ARG);
+            STAT_ACC(2);
+            npk = resolve_path(L, sc, P, pos, ntok, why, tpos STAT_ARG);
         }
-        // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
-        uint32_t reason = R_BAD;
-        reason = kind == K_EOB ? (uint32_t)R_EOB : reason;
-        reason = p + tb > end_bit ? (uint32_t)R_NEED_INPUT : reason;
-        reason = by_join ? (uint32_t)R_JOIN : reason;
-        reason = by_limit ? (uint32_t)R_LIMIT : reason;
-        const uint32_t jl = seg;
-        const uint32_t aux = reason == R_EOB ? p + cl : p;  // behind the end-of-block code / where the chains met / where the chain ends
-        WSYNC();  // rows complete; token stores have landed (the barrier's release waits for them)
-        STAT_ACC(2);
-        // ---- the true stream: lane 0's chain, then the chain it joined from the join on, and so on ----
-        const uint32_t nxt = reason == R_JOIN ? jl : 64u;
-        uint32_t a_join = 0;  // index, in the joined lane's row, of the token that starts at the join
-        if (reason == R_JOIN) {
-            const uint32_t off = aux - B - jl * S_BITS;
-#pragma unroll
-            for (int k = 0; k < ROW_WORDS; k++) {
-                int nb = (int)off - 32 * k;
-                nb = nb < 0 ? 0 : (nb > 32 ? 32 : nb);
-                const uint32_t below = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
-                a_join += __popc(L.rows[k * 64 + jl] & below);
-            }
-        }
-        // lanes on the path from lane 0, by pointer doubling over the join links (links only point forward);
-        // the two small arrays live in the input window, which is dead once the walk is over
-        uint32_t *const res_flags = L.inbuf, *const res_start = L.inbuf + 64;
-        bool on = lane == 0;
-        uint32_t jump = nxt;
-#pragma unroll
-        for (int r = 0; r < 6; r++) {
-            res_flags[lane] = 0;
-            WSYNC();
-            if (on && jump < 64u) res_flags[jump] = 1;
-            WSYNC();
-            on = on || res_flags[lane] != 0;
-            const uint32_t j2 = (uint32_t)__shfl((int)jump, (int)(jump & 63u), 64);
-            jump = jump < 64u ? j2 : 64u;
-            WSYNC();
-        }
-        if (on && nxt < 64u) res_start[nxt] = a_join;
-        WSYNC();
-        const uint32_t a0 = lane == 0 ? 0u : res_start[lane];
-        const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
-        const uint32_t incl = wave_incl_scan(cnt);
-        const uint64_t onm = __ballot(on);
-        const uint32_t lz = 63u - (uint32_t)__clzll((long long)onm);  // the piece the stream ends in
-        const uint32_t T = rdlane(incl, 63u);
-        const uint32_t rz = rdlane(reason, lz), az = rdlane(aux, lz);
-        // piece descriptors in stream order
-        const uint64_t nonempty = __ballot(cnt != 0);
-        if (cnt) {
-            const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt()), first = incl - cnt;
-            L.pk[2u * k] = first;
-            L.pk[2u * k + 1u] = ((a0 - first) & 0xffffu) | (row_base(lane) << 16);  // row token = stream index + (a0 - first)
-        }
-        WSYNC();
         STAT_ACC(3);
-        STAT_ADD(9, __popcll(onm));
-        STAT_ADD(10, T);
+        // the true stream, executed 64 pieces at a time
         int32_t st2 = ST_RUNNING;
-        const bool flushed = flush_tokens(L, grow, T, (uint32_t)__popcll(nonempty), gout, opos, cap, st2 STAT_ARG);
-        w.win0 = 0xffffffffu;  // the flush used the window as its token buffer
-        STAT_ACC(20);
+        bool flushed = true;
+        for (uint32_t b = 0; b < npk; b += 64) {
+            const uint32_t nb = npk - b < 64u ? npk - b : 64u;
+            WSYNC();  // the descriptions have landed; the flush before is done with the LDS
+            uint32_t f = 0, d = 0;
+            if (lane < nb) {
+                f = pathg[2u * (b + lane)];
+                d = pathg[2u * (b + lane) + 1u];
+            }
+            const uint32_t fend = b + 64u < npk ? pathg[2u * (b + 64u)] : ntok;  // same word in every lane
+            const uint32_t base = rdlane(f, 0);
+            L.fl.pk[2u * lane] = f - base;
+            L.fl.pk[2u * lane + 1u] = ((d + base) & 0xffffu) | (d & 0xffff0000u);
+            WSYNC();
+            STAT_ACC(7);
+            flushed = flush_tokens(L, sc.rows, rdfirst(fend) - base, nb, gout, opos, cap, st2 STAT_ARG);
+            STAT_ACC(20);
+            if (!flushed) break;
+        }
+        w.win0 = 0xffffffffu;  // the phases used the header window's place
         if (!flushed) {
             status = st2;
             return;
         }
-        if (rz == R_NEED_INPUT) {
+        if (why == R_NEED_INPUT) {
             status = CHIP_NEED_INPUT;
             return;
         }
-        if (rz == R_BAD) {
+        if (why == R_EOB) {
+            pos = tpos + eob_len;
+            return;
+        }
+        if (why != R_LIMIT || tpos <= pos) {  // invalid code (a round always gets past its first token otherwise)
             status = Z_DATA_ERROR;
             return;
         }
-        pos = az;
-        if (rz == R_EOB) return;
+        pos = tpos;  // the round ended before the block did: on from where the true stream stopped
     }
-}
-
-
-// After both alphabets are built: try to replace sorted[] by sub-tables (see build_subtables).
-__device__ CHIP_PHASE_FN void finish_tables(WaveLds &L)
-{
-    uint32_t *scratch = L.inbuf;  // free: the block header is parsed and decode_block stages its own window
-    WSYNC();
-    uint32_t n1 = build_subtables<LIT_ROOT>(L.lit_h, L.lit_sorted, L.lit_lut, scratch, 0);
-    uint32_t n2 = n1 == 0xffffffffu ? n1 : build_subtables<DIST_ROOT>(L.dist_h, L.dist_sorted, L.dist_lut, scratch, n1);
-    const bool ok = n1 != 0xffffffffu && n2 != 0xffffffffu;
-    WSYNC();
-    if (ok) {
-        const uint32_t n = n1 + n2;
-        uint32_t *sub = L.lit_sorted;  // lit_sorted[288] and dist_sorted[32] are contiguous: 320 entries
-        for (uint32_t i = lane_id(); i < n; i += 64) sub[i] = scratch[i];
-    }
-    if (lane_id() == 0) L.use_sub = ok ? 1u : 0u;
-    WSYNC();
 }
 
 #ifndef CHIP_WAVES_PER_SIMD
 #define CHIP_WAVES_PER_SIMD 4
 #endif
-// one unit, start to finish, by the calling wave; grow = the wave's token scratch rows
-__device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, uint32_t *grow)
+// one unit, start to finish, by the calling wave; scratch = the wave's token rows, piece records, path list and marks in HBM
+__device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, uint32_t *scratch)
 {
+    Scratch sc;
+    sc.rows = scratch;
+    sc.rec = (uint2 *)(scratch + ROWS_WORDS);
+    sc.path = scratch + ROWS_WORDS + 2 * PMAX;
+    sc.marks = scratch + ROWS_WORDS + 4 * PMAX;
     const uint32_t lane = lane_id();
 
     const uint8_t *gin = a.in_base + a.in_off[u];
@@ -1012,6 +1466,8 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     int32_t status = ST_RUNNING;
     bool last = false;
     int tables = 0;  // 0 none, 1 fixed, 2 dynamic
+    uint32_t eob_len = 0;   // length of the block's end-of-block code
+    bool serial = false;    // the block's tables do not fit the LDS pool: decode it with the serial fallback
 
     STAT_DECL;
     STAT_T0();
@@ -1037,7 +1493,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
     }
     if (!resumed && format != CHIP_FMT_DEFLATE) {
         uint32_t hdr = 0;
-        status = parse_wrapper(L.lit_lut, gin, in_len, format, wrap, hdr);
+        status = parse_wrapper((uint32_t *)&L, gin, in_len, format, wrap, hdr);
         status = (int32_t)rdfirst((uint32_t)status);
         wrap = rdfirst(wrap);
         pos += rdfirst(hdr) * 8u;
@@ -1095,17 +1551,14 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             status = Z_DATA_ERROR;
             break;
         }
+        uint32_t nlen = 288, ndist = 32;
+        bool build = true;
         if (type == 1) {
-            if (tables != 1) {
-                for (uint32_t s = lane; s < 288; s += 64) L.hdr.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            if (tables != 1) {  // RFC 1951 sec. 3.2.6 (a run of fixed blocks keeps its tables)
+                for (uint32_t s = lane; s < 320; s += 64) L.hdr.lens[s] = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5;
                 WSYNC();
-                build_table(L, L.hdr.lens, 288, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h);
-                if (lane < 32) L.hdr.lens[lane] = 5;
-                WSYNC();
-                build_table(L, L.hdr.lens, 32, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h);
-                finish_tables(L);
                 tables = 1;
-            }
+            } else build = false;
         } else {
             // dynamic block header, RFC 1951 sec. 3.2.7
             tables = 2;
@@ -1115,7 +1568,9 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             }
             win_ensure(L, w, pos);
             win_bits_uniform(L, w, pos, lo, hi);
-            uint32_t nlen = (lo & 31u) + 257, ndist = ((lo >> 5) & 31u) + 1, ncode = ((lo >> 10) & 15u) + 4;
+            nlen = (lo & 31u) + 257;
+            ndist = ((lo >> 5) & 31u) + 1;
+            const uint32_t ncode = ((lo >> 10) & 15u) + 4;
             pos += 14;
             if (nlen > 286 || ndist > 30) {
                 status = Z_DATA_ERROR;
@@ -1136,7 +1591,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
             }
             WSYNC();
             pos += 3 * ncode;
-            if (build_table(L, L.hdr.lens, 19, T_CODES, CL_ROOT, L.hdr.cl_lut, L.hdr.cl_sorted, L.hdr.cl_h)) {
+            if (build_cl_table(L)) {
                 status = Z_DATA_ERROR;
                 break;
             }
@@ -1196,18 +1651,22 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
                 status = Z_DATA_ERROR;
                 break;
             }
-            if (build_table(L, L.hdr.lens, (int)nlen, T_LENS, LIT_ROOT, L.lit_lut, L.lit_sorted, L.lit_h) ||
-                build_table(L, L.hdr.lens + nlen, (int)ndist, T_DISTS, DIST_ROOT, L.dist_lut, L.dist_sorted, L.dist_h)) {
+        }
+        if (build) {
+            eob_len = rdfirst(L.hdr.lens[256]);
+            uint32_t used = 0;
+            const int r1 = build_litlen(L, L.hdr.lens, (int)nlen, used);
+            const int r2 = r1 < 0 ? r1 : build_dist(L, L.hdr.lens + nlen, (int)ndist, r1 ? POOL_WORDS : used);
+            if (r1 < 0 || r2 < 0) {
                 status = Z_DATA_ERROR;
                 break;
             }
+            serial = r1 > 0 || r2 > 0;
             STAT_ACC(5);
-            finish_tables(L);
-            STAT_ACC(7);
         }
         STAT_ACC(0);
         __builtin_amdgcn_s_setprio(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status, grow, tables == 1 ? (uint32_t)XT_BITS_FIXED : (uint32_t)XT_BITS STAT_ARG);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status, sc, eob_len, serial STAT_ARG);
         __builtin_amdgcn_s_setprio(2);  // block headers and table builds are short dependent chains: ahead of the other waves' bulk work
         STAT_T0();
     }
@@ -1229,7 +1688,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
         } else {
             uint32_t want = gin[k] | ((uint32_t)gin[k + 1] << 8) | ((uint32_t)gin[k + 2] << 16) | ((uint32_t)gin[k + 3] << 24);
             const uint32_t c0 = run_cov - out_dropped;
-            if (rdfirst(wave_crc32(L.lit_lut, gout + c0, opos - c0, resumed ? run_check : 0u)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
+            if (rdfirst(wave_crc32((uint32_t *)&L, gout + c0, opos - c0, resumed ? run_check : 0u)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
             else if (in_len - k < 8) status = CHIP_NEED_INPUT;
             else {
                 uint32_t isize = gin[k + 4] | ((uint32_t)gin[k + 5] << 8) | ((uint32_t)gin[k + 6] << 16) | ((uint32_t)gin[k + 7] << 24);
@@ -1252,7 +1711,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
         if (!resumed) run_check = wrap == 1 ? 1u : 0u;
         const uint32_t c0 = run_cov - out_dropped;
         if (cont && wrap && ck_bit != 0 && ck_opos > c0) {
-            run_check = wrap == 1 ? wave_adler32(gout + c0, ck_opos - c0, run_check) : wave_crc32(L.lit_lut, gout + c0, ck_opos - c0, run_check);
+            run_check = wrap == 1 ? wave_adler32(gout + c0, ck_opos - c0, run_check) : wave_crc32((uint32_t *)&L, gout + c0, ck_opos - c0, run_check);
             run_cov = out_dropped + ck_opos;
         }
         if (lane == 0) {
@@ -1277,7 +1736,7 @@ __device__ void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, u
 __global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchArgs a, uint32_t *scratch, uint32_t *next_unit)
 {
     __shared__ WaveLds L;
-    uint32_t *grow = scratch + (size_t)blockIdx.x * SCRATCH_WORDS_PER_WAVE;
+    uint32_t *grow = scratch + (size_t)blockIdx.x * SCRATCH_WORDS;
     const uint32_t limit = a.sel_n ? *a.sel_n : a.n;
     for (;;) {
         uint32_t i = 0;
@@ -1304,13 +1763,13 @@ std::mutex g_slot_mu;
 std::map<std::pair<int, hipStream_t>, LaunchSlot> g_slots;
 
 // The slot of (current device, stream), with token scratch for min(n, resident waves) waves: a streaming decoder
-// (batches of one) holds 48 KiB, not the 200 MB a full grid needs; the scratch grows when a larger batch arrives.
+// (batches of one) holds 200 KB, not the 0.8 GB a full grid needs; the scratch grows when a larger batch arrives.
+// (caller holds g_slot_mu)
 hipError_t slot_for(hipStream_t stream, uint32_t n, LaunchSlot &out)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(g_slot_mu);
     LaunchSlot &sl = g_slots[{dev, stream}];
     static int max_blocks[64] = {0};  // resident waves of a full grid, per device
     const int di = dev < 64 ? dev : 63;
@@ -1330,9 +1789,9 @@ hipError_t slot_for(hipStream_t stream, uint32_t n, LaunchSlot &out)
         // a little headroom for batches that grow slowly (streaming objects stay at one wave)
         const int blocks = want <= 1 ? 1 : (want + want / 4 < max_blocks[di] ? want + want / 4 : max_blocks[di]);
         uint32_t *p = nullptr;
-        if ((e = hipMalloc((void **)&p, (size_t)blocks * SCRATCH_WORDS_PER_WAVE * 4 + 256)) != hipSuccess) return e;
+        if ((e = hipMalloc((void **)&p, (size_t)blocks * SCRATCH_WORDS * 4 + 256)) != hipSuccess) return e;
         sl.scratch = p;
-        sl.counter = p + (size_t)blocks * SCRATCH_WORDS_PER_WAVE;
+        sl.counter = p + (size_t)blocks * SCRATCH_WORDS;
         sl.blocks = blocks;
     }
     out = sl;
@@ -1398,12 +1857,14 @@ void release_inflate_scratch_of(hipStream_t stream)
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
 {
     if (a.n == 0) return hipSuccess;
+    // One lock from the slot's lookup to the launch: a second host thread that launches a larger batch on the same stream may
+    // free and reallocate the scratch in slot_for(); it must not do so between this thread's lookup and its launch (the
+    // stream synchronisation in slot_for() only covers work that is already queued).  The counter reset and the kernel also
+    // have to reach the stream back to back.
+    std::lock_guard<std::mutex> lk(g_slot_mu);
     LaunchSlot sl;
     hipError_t e = slot_for(stream, a.n, sl);
     if (e != hipSuccess) return e;
-    // counter reset and kernel must reach the stream back to back even when several host threads launch on it
-    static std::mutex enqueue_mu;
-    std::lock_guard<std::mutex> lk(enqueue_mu);
     if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
     const uint32_t blocks = a.n < (uint32_t)sl.blocks ? a.n : (uint32_t)sl.blocks;
     hipLaunchKernelGGL(inflate_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
