@@ -90,6 +90,11 @@ __device__ __forceinline__ int32_t detect_kind(const uint8_t *b, uint32_t len)
     return (b0 == 0x28 && b1 == 0xb5 && b[2] == 0x2f && b[3] == 0xfd) ? CHIP_DETECT_ZSTD : CHIP_DETECT_UNKNOWN;
 }
 
+// address spaces: LDS pointers keep theirs through calls and selects (a generic pointer to LDS becomes flat accesses), pointers
+// into HBM keep theirs through scalar round trips
+#define LDS_AS __attribute__((address_space(3)))
+#define GAS __attribute__((address_space(1)))
+
 // ---- wavefront helpers (wave = 64 lanes, one wave per workgroup in the codec kernels) ----------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }

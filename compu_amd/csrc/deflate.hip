@@ -907,7 +907,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
     }
     // ---- checksum / trailer -----------------------------------------------------------------------
     uint32_t check = a.check_seed;
-    if (fmt == CHIP_FMT_GZIP) check = wave_crc32(L.table, gin, n, a.check_seed);  // the hash table is dead by now
+    if (fmt == CHIP_FMT_GZIP) check = wave_crc32((LDS_AS uint32_t *)L.table, gin, n, a.check_seed);  // the hash table is dead by now
     else if (fmt == CHIP_FMT_ZLIB) check = wave_adler32(gin, n, a.check_seed);
     if (trl && fmt == CHIP_FMT_GZIP) {
         const uint32_t isize = (uint32_t)(a.total_before + n);

@@ -29,7 +29,6 @@ namespace chip {
 
 // pointers into HBM keep their address space through the scalar round trip of rdfirst_ptr (else every access through them is a
 // flat one: slower, and counted as an LDS access too)
-#define GAS __attribute__((address_space(1)))
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // at any byte address (gfx950 takes any alignment for global and LDS accesses)
@@ -127,12 +126,22 @@ constexpr uint32_t S_BITS = 256, S_SHIFT = 8;
 constexpr uint32_t RING_CHUNKS = CHIP_RING_CHUNKS;
 constexpr uint32_t RING_DW = 64 * RING_CHUNKS;
 constexpr uint32_t RING_BYTES = 4 * RING_DW;
-constexpr uint32_t PMAX = 768;         // segments (= pieces of the token stream) per walk round
+#ifndef CHIP_PMAX
+#define CHIP_PMAX 768
+#define CHIP_ROW_TOKENS 640
+#endif
+constexpr uint32_t PMAX = CHIP_PMAX;         // segments (= pieces of the token stream) per walk round
 constexpr uint32_t PIECE_ITERS = PMAX / 64;
-constexpr uint32_t ROW_TOKENS = 640;   // tokens a lane can record per walk round
-constexpr uint32_t PIECE_TOKENS = 240; // tokens per piece (8-bit counts)
-constexpr uint32_t TRIP = 8;           // tokens per lane between two maintenance steps (claims, window, records)
+constexpr uint32_t ROW_TOKENS = CHIP_ROW_TOKENS;   // tokens a lane can record per walk round
+#ifndef CHIP_TRIP
+#define CHIP_TRIP 8
+#endif
+constexpr uint32_t TRIP = CHIP_TRIP;           // tokens per lane between two maintenance steps (claims, window, records)
 static_assert(PMAX % 64 == 0 && PMAX <= 1024 && ROW_TOKENS % 4 == 0 && 8u * ROW_TOKENS * 7u + 28u < 65536u && TRIP % 4 == 0, "geometry");
+#ifndef CHIP_XT_BITS
+#define CHIP_XT_BITS 2048
+#endif
+constexpr uint32_t XT_BITS = CHIP_XT_BITS;  // how far past its own segment a chain may run before it is cut
 constexpr uint32_t HDR_IN_DW = 192;    // input window of the block-header parser, dwords (the code lengths take <= 4584 bits)
 
 // Scratch of a wave in HBM: the lanes' token rows, then one record per piece, then the list of pieces on the true path.
@@ -145,8 +154,9 @@ __device__ __forceinline__ uint32_t row_word(uint32_t k) { return k + (k >> 2) *
 
 // token: [8:0] literal byte, or match length 3..258; [9] match; [25:10] match distance - 1; [31:26] bits the token took in the
 // stream (the walk's flush preparation finds a piece's entry token by adding these up)
-// piece record (two words): .x = bit position the chain stopped at; .y = [5:0] lane, [15:6] first row token, [23:16] tokens, [26:24] reason
+// piece record (two words): .x = bit position the chain stopped at; .y = [5:0] lane, [15:6] first row token, [25:16] tokens, [28:26] reason
 enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
+enum : uint32_t { LK_FAR = 251, LK_EOB = 252, LK_END = 253 };  // link[]: joined a piece more than 250 further on; end-of-block code; any other end
 
 struct HuffMeta {
     uint32_t limit15[16];  // [l] = end (exclusive) of the 15-bit-aligned code space of lengths <= l; [0] = 0
@@ -169,7 +179,7 @@ constexpr uint32_t TOK_RING = 4;   // token groups on their way from the scratch
 static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0 && IMG_WORDS % 2 == 0, "geometry");
 
 constexpr uint32_t PHASE_BYTES = 4 * (RING_DW + 2) + 4 * RING_DW;  // the walk's two rings are the largest phase
-constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - 32 - PHASE_BYTES) / 4;
+constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - 128 - PHASE_BYTES) / 4;
 constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;
 
 struct alignas(16) WaveLds {
@@ -205,7 +215,7 @@ struct alignas(16) WaveLds {
     uint16_t lit_root[1 << LIT_ROOT];
     uint16_t dist_root[1 << DIST_ROOT];
     uint32_t pool[POOL_WORDS];  // literal/length finals and sub-tables from the bottom, distance sub-tables (16-bit) from the top
-    uint32_t jbits[4], ebits[4];  // pieces of the last 128 claimed (bit = index mod 128): joined by another chain / ended on an end-of-block code
+    uint8_t link[128];  // of the last 128 pieces claimed (index mod 128): 0 running; 1..250 joined the piece that many further on; LK_* how else it ended
 };
 static_assert(sizeof(WaveLds) <= 10240, "16 waves per CU: LDS is granted in 1280-byte steps");
 static_assert(offsetof(WaveLds, hdr.lit_sorted) >= offsetof(WaveLds, fl.pk) + 512, "the fallback's tables survive the flush");
@@ -483,7 +493,7 @@ __device__ __forceinline__ uint32_t bfe(uint32_t v, uint32_t off, uint32_t width
 
 // zlib / gzip header (RFC 1950 sec. 2.2, RFC 1952 sec. 2.3), checks in zlib's order.  Returns
 // ST_RUNNING and the header length in bytes, or the final status (need-input / error / need-dict).
-__device__ int32_t parse_wrapper(uint32_t *tab, const uint8_t *gin, uint32_t avail, int32_t format, uint32_t &wrap, uint32_t &hdr)
+__device__ int32_t parse_wrapper(LDS_AS uint32_t *tab, const uint8_t *gin, uint32_t avail, int32_t format, uint32_t &wrap, uint32_t &hdr)
 {
     wrap = 0;
     hdr = 0;
@@ -547,7 +557,6 @@ __device__ int32_t parse_wrapper(uint32_t *tab, const uint8_t *gin, uint32_t ava
 struct __attribute__((packed)) U32u { uint32_t v; };
 struct __attribute__((packed)) U16u { uint16_t v; };
 struct __attribute__((packed)) U128u { uint32_t x, y, z, w; };
-#define LDS_AS __attribute__((address_space(3)))
 typedef LDS_AS uint8_t lds_u8;
 
 // Stored-block payload: copy n bytes from byte offset `so` of the unit's input to gdst.  Byte copies bring the
@@ -941,8 +950,9 @@ struct Scratch {
     uint2 *rec;       // [PMAX] piece records
     uint32_t *path;   // [PMAX] two words per non-empty piece of the true path, in stream order (the flush's piece descriptions)
     uint32_t *marks;  // [8 * PMAX + 64] the round's mark bits (spilled from the ring as its chunks are replaced)
+    uint32_t *dump;   // [256] where a lane that took no token in a group of four puts the group (the walk counts its stores)
 };
-constexpr size_t SCRATCH_WORDS = ROWS_WORDS + 2 * PMAX + 2 * PMAX + 8 * PMAX + 64;
+constexpr size_t SCRATCH_WORDS = ROWS_WORDS + 2 * PMAX + 2 * PMAX + 8 * PMAX + 64 + 256;
 
 constexpr uint32_t NONE = 0xffffffffu;
 
@@ -975,10 +985,8 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         return i < total_dw ? g32[i] : 0u;
     };
     WSYNC();  // the phase before (header parse, previous flush) is done with the rings' place
-    if (lane < 4) {
-        L.jbits[lane] = lane == 0 ? 1u : 0u;  // piece 0 starts on the true stream
-        L.ebits[lane] = 0;
-    }
+    L.link[lane] = 0;
+    L.link[64u + lane] = 0;
     // the first chunks: all loads go out before the first LDS store waits for one
     uint32_t cload = cmax < RING_CHUNKS ? cmax : RING_CHUNKS;
     {
@@ -993,13 +1001,10 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         if (lane < 2) L.ring.win[RING_DW + lane] = v[0];
     }
     uint32_t slot = cload == RING_CHUNKS ? 0u : cload;  // ring slot of chunk cload
-    uint32_t preA = cload < cmax ? chunk_word(cload) : 0u;          // chunks cload and cload + 1 on their way: even chunk numbers in
-    uint32_t preB = cload + 1 < cmax ? chunk_word(cload + 1) : 0u;  // one register, odd ones in the other
-    if (cload & 1u) {
-        const uint32_t t = preA;
-        preA = preB;
-        preB = t;
-    }
+    uint32_t cissued = cload;  // chunks asked for (the ring's later chunks arrive by LDS-DMA: no register holds a load in flight)
+    bool padfix = false;
+    const uint32_t win_lds = rdfirst((uint32_t)(uintptr_t)(LDS_AS uint32_t *)L.ring.win);
+    GAS uint32_t *const mydump = rdfirst_gptr(sc.dump) + 4u * lane;
     LSYNC();
     STAT_ACC(1);
     STAT_ADD(8, 1);
@@ -1010,10 +1015,20 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
     uint32_t jb = 0, z = 0, pn = 0;    // of the lane's last token: join bit, halt flags, end position
     bool stopped = false;              // the lane's last token was not taken
     // wave state
-    uint32_t next_seg = 0, dl = 0, epoch = 0;
-    bool draining = false;
+    uint32_t next_seg = 0, dl = 0, epoch = 0, T = 0;
+    bool draining = false, pend = false, lost = false;
     for (;;) {
         // ======== maintenance: blocked lanes, finished pieces, window, claims ========
+        STAT_ACC(15);
+        if (cissued != cload) {
+            // The chunks asked for in the step before have landed once at most the trip's token stores (TRIP / 4 of them, always
+            // issued) are outstanding: vector memory operations complete in order.
+            static_assert(TRIP / 4 == 2, "the wait below counts the trip's stores");
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (padfix && lane < 2) L.ring.win[RING_DW + lane] = L.ring.win[lane];
+            padfix = false;
+            cload = cissued;
+        }
         const uint32_t F = gbit + (next_seg << S_SHIFT);  // first bit nobody has claimed
         bool held = seg != NONE;
         if (stopped) {  // why the lane's last token was not taken, in zlib's order of verdicts
@@ -1028,50 +1043,95 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         stopped = false;
         if (held && stop == R_RUN) {
             if (draining && p >= F) stop = R_LIMIT;  // nobody will mark a boundary out there any more
-            if (nst >= PIECE_TOKENS || rowstart + nst + TRIP + 4u > ROW_TOKENS) stop = R_LIMIT;
+            if (rowstart + nst + TRIP + 4u > ROW_TOKENS) stop = R_LIMIT;  // the lane's row is full
+            // a chain that has run XT_BITS past its segment without meeting another holds the ring's oldest chunks, and with them every
+            // claim (fixed-Huffman data with runs of one byte keeps two parses apart for ever): cut it; if it carried the true stream the
+            // round ends there and the next one starts on it
+            if (p - own_end > XT_BITS && p > own_end) stop = R_LIMIT;
         }
         bool fin = held && stop != R_RUN;
-        uint64_t trig = 0;
+        bool ended = false;  // the true stream has ended (end of block, invalid code, input exhausted, a chain cut short)
         if (__any(fin)) {
-            const uint32_t jseg = (p - gbit) >> S_SHIFT;
-            if (fin && stop == R_JOIN) atomicOr(&L.jbits[(jseg >> 5) & 3u], 1u << (jseg & 31u));
-            if (fin && stop == R_EOB && next_seg - seg < 128u) atomicOr(&L.ebits[(seg >> 5) & 3u], 1u << (seg & 31u));
-            LSYNC();
-            // an end-of-block code on a chain that another chain has joined (or that started the round) ends the round at once:
-            // a guess -- the path resolve below is what decides -- that keeps the walk from running on into the next block
-            bool t = false;
-            if (fin && stop == R_JOIN) t = (L.ebits[(jseg >> 5) & 3u] >> (jseg & 31u)) & 1u;
-            if (fin && stop == R_EOB && next_seg - seg < 128u) t = (L.jbits[(seg >> 5) & 3u] >> (seg & 31u)) & 1u;
-            trig = __ballot(t);
-            if (trig) {
-                if (held && stop == R_RUN) stop = R_LIMIT;
-                fin = held;
-            }
+            const uint32_t jd = ((p - gbit) >> S_SHIFT) - seg;
+            const uint32_t code = stop == R_JOIN ? (jd < LK_FAR ? jd : (uint32_t)LK_FAR) : stop == R_EOB ? (uint32_t)LK_EOB : (uint32_t)LK_END;
+            if (fin && next_seg - seg <= 128u) L.link[seg & 127u] = (uint8_t)code;  // (an older piece's place has gone to a newer one)
+            const uint64_t endm = __ballot(fin && stop != R_JOIN);
+            if (endm && !lost) pend = true;  // such an end counts if it lies on the true stream: find out below
             if (fin) {
-                recg[seg] = u32x2{p, lane | (rowstart << 6) | (nst << 16) | (stop << 24)};
+                recg[seg] = u32x2{p, lane | (rowstart << 6) | (nst << 16) | (stop << 26)};
                 rowpos = (rowstart + nst + 3u) & ~3u;
                 seg = NONE;
                 stop = R_RUN;
             }
+            LSYNC();
         }
-        if (trig) break;
+        STAT_ACC(12);
+        // ---- the true stream's piece: piece T carries it as far as is known.  Follow the links of finished pieces from T (pointer
+        // doubling over the 128 pieces from T on, two per lane, links fetched with ds_bpermute) when a chain has ended somewhere
+        // in front, or before the pieces' places in link[] run out.
+        while (!lost && (pend || next_seg - T > 96u)) {
+            const uint32_t k0 = T + lane, k1 = T + 64u + lane;
+            const uint32_t v0 = k0 < next_seg ? L.link[k0 & 127u] : 0u, v1 = k1 < next_seg ? L.link[k1 & 127u] : 0u;
+            uint32_t l0 = (v0 - 1u < 250u && lane + v0 < 128u) ? lane + v0 : lane;
+            uint32_t l1 = (v1 - 1u < 250u && 64u + lane + v1 < 128u) ? 64u + lane + v1 : 64u + lane;
+#pragma unroll
+            for (int r = 0; r < 7; r++) {
+                const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l0 << 2), (int)l0), b0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l0 << 2), (int)l1);
+                const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l1 << 2), (int)l0), b1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l1 << 2), (int)l1);
+                l0 = l0 < 64u ? a0 : b0;
+                l1 = l1 < 64u ? a1 : b1;
+            }
+            const uint32_t Tn = T + rdlane(l0, 0);  // the last piece the links lead to
+            const uint32_t ti = Tn - T;
+            const uint32_t c = ti < 64u ? rdlane(v0, ti & 63u) : rdlane(v1, ti & 63u);  // how it ended, if it has
+            const bool moved = Tn != T;
+            T = Tn;
+            if (c >= LK_EOB) {
+                ended = true;
+                break;
+            }
+            if (c == LK_FAR) {  // (a chain that ran over more than 250 segments: not followed; the round then runs its full length)
+                lost = true;
+                pend = false;
+                break;
+            }
+            // ends in front of T are still open; those behind it are not on the stream
+            pend = __any((v0 >= LK_EOB && k0 > T) || (v1 >= LK_EOB && k1 > T));
+            if (c == 0 || !moved) break;  // T is running (or its link leads out of the window: next time)
+        }
+        if (ended) {  // nothing behind that end is of use: the round is over
+            held = seg != NONE;
+            if (held) {
+                recg[seg] = u32x2{p, lane | (rowstart << 6) | (nst << 16) | (R_LIMIT << 26)};
+                seg = NONE;
+            }
+            STAT_ADD(22, 1);
+            break;
+        }
+        STAT_ACC(14);
         held = seg != NONE;
-        // ---- window: up to two chunks per step, each replacing the ring's oldest once no lane is in front of its end
+        // ---- window: up to two chunks per step are asked for, each replacing the ring's oldest once no lane is in front of its end;
+        // they count as loaded from the next maintenance step on
         {
             dl = wave_min_u32(held ? (p >> 5) - D0 : 8u * next_seg);  // lowest dword (from D0) a lane may still touch
 #pragma unroll
             for (int r = 0; r < 2; r++) {
-                if (cload < cmax && dl >= 64u * (cload - RING_CHUNKS + 1u)) {
-                    const uint32_t v = (cload & 1u) ? preB : preA;
+                if (cissued < cmax && dl >= 64u * (cissued - RING_CHUNKS + 1u)) {
                     const uint32_t old = L.ring.bm[64u * slot + lane];
-                    marks[64u * (cload - RING_CHUNKS) + lane] = old;  // the marks of the chunk that leaves the ring
-                    L.ring.win[64u * slot + lane] = v;
+                    marks[64u * (cissued - RING_CHUNKS) + lane] = old;  // the marks of the chunk that leaves the ring
                     L.ring.bm[64u * slot + lane] = 0;
-                    if (slot == 0 && lane < 2) L.ring.win[RING_DW + lane] = v;
-                    const uint32_t nx = cload + 2u < cmax ? chunk_word(cload + 2u) : 0u;
-                    if (cload & 1u) preB = nx;
-                    else preA = nx;
-                    cload++;
+                    const uint32_t i = D0 + 64u * cissued + lane;
+                    if (i < total_dw) {  // (dwords behind the input keep what the slot held: no token can use them)
+                        const GAS uint32_t *src = g32 + i;
+                        const uint32_t dst = win_lds + 256u * slot;
+                        uint32_t keep;
+                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                                     : "=&s"(keep)
+                                     : "v"(src), "s"(dst)
+                                     : "memory");
+                    }
+                    if (slot == 0) padfix = true;
+                    cissued++;
                     slot = slot + 1u == RING_CHUNKS ? 0u : slot + 1u;
                 }
             }
@@ -1092,6 +1152,9 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
                     const uint32_t lw = 8u * cload - 1u;  // segment k reads up to dword 8 k + 10
                     lim = lim < lw ? lim : lw;
                 }
+                const uint32_t lt = lost ? 0xffffffffu : T + 128u;  // a piece has a place in link[] until the piece 128 further on is claimed
+                lim = lim < lt ? lim : lt;
+                if (pend) lim = next_seg;  // a chain has ended in front of the true stream: no new pieces until it is known whether it counts
             }
             const uint64_t fm = __ballot(want);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
@@ -1102,10 +1165,7 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
                 own_end = gbit + ((k + 1u) << S_SHIFT);
                 rowstart = rowpos;
                 nst = 0;
-                if (k != 0) {
-                    atomicAnd(&L.jbits[(k >> 5) & 3u], ~(1u << (k & 31u)));
-                    atomicAnd(&L.ebits[(k >> 5) & 3u], ~(1u << (k & 31u)));
-                }
+                L.link[k & 127u] = 0;
             }
             const uint32_t nfree = (uint32_t)__popcll(fm), room = lim > next_seg ? lim - next_seg : 0u;
             const uint32_t ncl = nfree < room ? nfree : room;
@@ -1123,6 +1183,7 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         while (dl >= epoch + RING_DW) epoch += RING_DW;
         const uint32_t base4 = 4u * (D0 + epoch);
         STAT_ADD(11, 1);
+        STAT_ACC(13);
         // ======== a trip: TRIP tokens per running lane ========
         // A token's work is straight-line code; a lane whose token cannot be taken (it joined another chain, met an end-of-block or
         // invalid code, or the token ends behind `hard`) drops out of the trip with jb / z / pn as that step left them: the next
@@ -1176,7 +1237,8 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
                 }
                 run = ok;
             }
-            if (ran && nst > ng) *(GAS u32x4 *)(myrow + 8u * (rowstart + ng)) = u32x4{t4[0], t4[1], t4[2], t4[3]};
+            // (always issued: the maintenance step's wait for the window chunks counts these stores)
+            *(GAS u32x4 *)((ran && nst > ng) ? myrow + 8u * (rowstart + ng) : mydump) = u32x4{t4[0], t4[1], t4[2], t4[3]};
             STAT_ADD(21, __popcll(__ballot(ran)));
         }
         stopped = seg != NONE && !run;
@@ -1209,12 +1271,17 @@ __device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, co
 #pragma unroll
     for (uint32_t i = 0; i < PIECE_ITERS; i++) {
         const uint32_t k = 64u * i + lane;
-        u32x2 r = u32x2{0, R_LIMIT << 24};
-        if (k < P) r = recg[k];
-        q[i] = r.x - gbit;
-        info[i] = r.y;
-        nx[i] = ((r.y >> 24) & 7u) == R_JOIN ? q[i] >> S_SHIFT : k;
-        L.res.nxt[k] = (uint16_t)nx[i];
+        q[i] = 0;
+        info[i] = R_LIMIT << 26;
+        nx[i] = k;
+        if (64u * i < P) {  // uniform: a short round costs as many steps as it has pieces
+            u32x2 r = u32x2{0, R_LIMIT << 26};
+            if (k < P) r = recg[k];
+            q[i] = r.x - gbit;
+            info[i] = r.y;
+            nx[i] = (r.y >> 26) == R_JOIN ? q[i] >> S_SHIFT : k;
+            L.res.nxt[k] = (uint16_t)nx[i];
+        }
     }
     if (lane < PMAX / 32) L.res.on[lane] = lane == 0 ? 1u : 0u;
     LSYNC();
@@ -1225,7 +1292,7 @@ __device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, co
 #pragma unroll
         for (uint32_t i = 0; i < PIECE_ITERS; i++) {
             const uint32_t k = 64u * i + lane;
-            nn[i] = nx[i];
+            nn[i] = 0;
             if (64u * i < P) {
                 const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
                 if (on && nx[i] != k) atomicOr(&L.res.on[nx[i] >> 5], 1u << (nx[i] & 31u));
@@ -1235,8 +1302,10 @@ __device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, co
         LSYNC();
 #pragma unroll
         for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-            nx[i] = nn[i];
-            if (64u * i < P) L.res.nxt[64u * i + lane] = (uint16_t)nn[i];
+            if (64u * i < P) {
+                nx[i] = nn[i];
+                L.res.nxt[64u * i + lane] = (uint16_t)nn[i];
+            }
         }
         LSYNC();
     }
@@ -1245,32 +1314,75 @@ __device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, co
     LSYNC();
 #pragma unroll
     for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-        const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
-        if (64u * i < P && on && ((info[i] >> 24) & 7u) == R_JOIN) entry[q[i] >> S_SHIFT] = (uint8_t)(q[i] & (S_BITS - 1u));
+        if (64u * i < P) {
+            const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
+            if (on && (info[i] >> 26) == R_JOIN) entry[q[i] >> S_SHIFT] = (uint8_t)(q[i] & (S_BITS - 1u));
+        }
     }
     LSYNC();
-    // descriptions in stream order; a piece's first token on the stream = the boundaries its owner marked in front of the entry
-    uint32_t npk = 0, ntok = 0, kz = 0;
+    // how the stream ends: the last piece of the path
+    {
+        uint32_t kz = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-        if (64u * i < P) {  // uniform
-            const uint32_t k = 64u * i + lane;
-            const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
-            const uint64_t onm = __ballot(on);
-            if (onm) kz = 64u * i + 63u - (uint32_t)__clzll((long long)onm);
-            uint32_t a0 = 0;
+        for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+            if (64u * i < P) {
+                const uint64_t onm = __ballot((L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u);
+                if (onm) kz = 64u * i + 63u - (uint32_t)__clzll((long long)onm);
+            }
+        }
+        const uint32_t zi = kz >> 6, zl = kz & 63u;
+        uint32_t wq = 0, wi = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < PIECE_ITERS; i++)
+            if (i == zi) {
+                wq = rdlane(q[i], zl);
+                wi = rdlane(info[i], zl);
+            }
+        term_why = wi >> 26;
+        term_pos = wq + gbit;
+    }
+    // a piece's first token on the stream = the boundaries its owner marked in front of the entry (from the spilled marks: the
+    // loads of two pieces per lane are in flight together)
+    uint32_t a0s[PIECE_ITERS];
+#pragma unroll
+    for (uint32_t i0 = 0; i0 < PIECE_ITERS; i0 += 2) {
+        if (64u * i0 >= P) break;
+        u32x4 m[2][2];
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t i = i0 + j, k = 64u * i + lane;
+            const bool on = i < PIECE_ITERS && 64u * i < P && ((L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u);
+            m[j][0] = m[j][1] = u32x4{0, 0, 0, 0};
             if (on) {
-                const uint32_t eo = entry[k];
-                const u32x4 m0 = *(GAS const u32x4 *)(marks + 8u * k), m1 = *(GAS const u32x4 *)(marks + 8u * k + 4u);
-                const uint32_t mw[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+                m[j][0] = *(GAS const u32x4 *)(marks + 8u * k);
+                m[j][1] = *(GAS const u32x4 *)(marks + 8u * k + 4u);
+            }
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 2; j++) {
+            const uint32_t i = i0 + j;
+            if (i < PIECE_ITERS) {
+                const uint32_t eo = entry[64u * i + lane];
+                const uint32_t mw[8] = {m[j][0].x, m[j][0].y, m[j][0].z, m[j][0].w, m[j][1].x, m[j][1].y, m[j][1].z, m[j][1].w};
+                uint32_t c = 0;
 #pragma unroll
                 for (uint32_t wd = 0; wd < 8; wd++) {
                     const int32_t nb = (int32_t)eo - 32 * (int32_t)wd;
                     const uint32_t msk = nb <= 0 ? 0u : nb >= 32 ? 0xffffffffu : (1u << nb) - 1u;
-                    a0 += __popc(mw[wd] & msk);
+                    c += __popc(mw[wd] & msk);
                 }
+                a0s[i] = c;
             }
-            const uint32_t nst = (info[i] >> 16) & 255u;
+        }
+    }
+    // descriptions in stream order
+    uint32_t npk = 0, ntok = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
+        if (64u * i < P) {  // uniform
+            const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
+            const uint32_t a0 = a0s[i];
+            const uint32_t nst = (info[i] >> 16) & 1023u;
             const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
             const uint32_t incl = wave_incl_scan(cnt);
             const uint64_t nonempty = __ballot(cnt != 0);
@@ -1284,19 +1396,6 @@ __device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, co
             npk += (uint32_t)__popcll(nonempty);
             ntok += rdlane(incl, 63u);
         }
-    }
-    // how the stream ends: the last piece of the path
-    {
-        const uint32_t zi = kz >> 6, zl = kz & 63u;
-        uint32_t wq = 0, wi = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < PIECE_ITERS; i++)
-            if (i == zi) {
-                wq = rdlane(q[i], zl);
-                wi = rdlane(info[i], zl);
-            }
-        term_why = (wi >> 24) & 7u;
-        term_pos = wq + gbit;
     }
     ntok_out = ntok;
     STAT_ADD(9, npk);
@@ -1393,24 +1492,31 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
             npk = resolve_path(L, sc, P, pos, ntok, why, tpos STAT_ARG);
         }
         STAT_ACC(3);
-        // the true stream, executed 64 pieces at a time
+        // the true stream, executed 64 pieces at a time; a batch's descriptions are fetched while the batch before it is executed
         int32_t st2 = ST_RUNNING;
         bool flushed = true;
+        WSYNC();  // the descriptions have landed
+        uint32_t f = 0, d = 0, fend = ntok;
+        if (lane < npk) {
+            f = pathg[2u * lane];
+            d = pathg[2u * lane + 1u];
+        }
+        if (64u < npk) fend = pathg[2u * 64u];  // same word in every lane
         for (uint32_t b = 0; b < npk; b += 64) {
             const uint32_t nb = npk - b < 64u ? npk - b : 64u;
-            WSYNC();  // the descriptions have landed; the flush before is done with the LDS
-            uint32_t f = 0, d = 0;
-            if (lane < nb) {
-                f = pathg[2u * (b + lane)];
-                d = pathg[2u * (b + lane) + 1u];
-            }
-            const uint32_t fend = b + 64u < npk ? pathg[2u * (b + 64u)] : ntok;  // same word in every lane
+            WSYNC();  // the flush before is done with the LDS
             const uint32_t base = rdlane(f, 0);
             L.fl.pk[2u * lane] = f - base;
             L.fl.pk[2u * lane + 1u] = ((d + base) & 0xffffu) | (d & 0xffff0000u);
+            const uint32_t T = rdfirst(fend) - base;
+            if (b + 64u + lane < npk) {
+                f = pathg[2u * (b + 64u + lane)];
+                d = pathg[2u * (b + 64u + lane) + 1u];
+            }
+            fend = b + 128u < npk ? pathg[2u * (b + 128u)] : ntok;
             WSYNC();
             STAT_ACC(7);
-            flushed = flush_tokens(L, sc.rows, rdfirst(fend) - base, nb, gout, opos, cap, st2 STAT_ARG);
+            flushed = flush_tokens(L, sc.rows, T, nb, gout, opos, cap, st2 STAT_ARG);
             STAT_ACC(20);
             if (!flushed) break;
         }
@@ -1427,6 +1533,7 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
             pos = tpos + eob_len;
             return;
         }
+        STAT_ADD(23, 1);
         if (why != R_LIMIT || tpos <= pos) {  // invalid code (a round always gets past its first token otherwise)
             status = Z_DATA_ERROR;
             return;
@@ -1446,6 +1553,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
     sc.rec = (uint2 *)(scratch + ROWS_WORDS);
     sc.path = scratch + ROWS_WORDS + 2 * PMAX;
     sc.marks = scratch + ROWS_WORDS + 4 * PMAX;
+    sc.dump = scratch + ROWS_WORDS + 4 * PMAX + 8 * PMAX + 64;
     const uint32_t lane = lane_id();
 
     const uint8_t *gin = a.in_base + a.in_off[u];
@@ -1493,7 +1601,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
     }
     if (!resumed && format != CHIP_FMT_DEFLATE) {
         uint32_t hdr = 0;
-        status = parse_wrapper((uint32_t *)&L, gin, in_len, format, wrap, hdr);
+        status = parse_wrapper((LDS_AS uint32_t *)&L, gin, in_len, format, wrap, hdr);
         status = (int32_t)rdfirst((uint32_t)status);
         wrap = rdfirst(wrap);
         pos += rdfirst(hdr) * 8u;
@@ -1688,7 +1796,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
         } else {
             uint32_t want = gin[k] | ((uint32_t)gin[k + 1] << 8) | ((uint32_t)gin[k + 2] << 16) | ((uint32_t)gin[k + 3] << 24);
             const uint32_t c0 = run_cov - out_dropped;
-            if (rdfirst(wave_crc32((uint32_t *)&L, gout + c0, opos - c0, resumed ? run_check : 0u)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
+            if (rdfirst(wave_crc32((LDS_AS uint32_t *)&L, gout + c0, opos - c0, resumed ? run_check : 0u)) != rdfirst(want)) status = Z_DATA_ERROR;  // incorrect data check
             else if (in_len - k < 8) status = CHIP_NEED_INPUT;
             else {
                 uint32_t isize = gin[k + 4] | ((uint32_t)gin[k + 5] << 8) | ((uint32_t)gin[k + 6] << 16) | ((uint32_t)gin[k + 7] << 24);
@@ -1711,7 +1819,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
         if (!resumed) run_check = wrap == 1 ? 1u : 0u;
         const uint32_t c0 = run_cov - out_dropped;
         if (cont && wrap && ck_bit != 0 && ck_opos > c0) {
-            run_check = wrap == 1 ? wave_adler32(gout + c0, ck_opos - c0, run_check) : wave_crc32((uint32_t *)&L, gout + c0, ck_opos - c0, run_check);
+            run_check = wrap == 1 ? wave_adler32(gout + c0, ck_opos - c0, run_check) : wave_crc32((LDS_AS uint32_t *)&L, gout + c0, ck_opos - c0, run_check);
             run_cov = out_dropped + ck_opos;
         }
         if (lane == 0) {

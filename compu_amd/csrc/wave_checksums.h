@@ -41,9 +41,12 @@ __device__ __forceinline__ void lane_chunk(uint32_t n, uint32_t &chunk_log2, uin
 // CRC-32 (RFC 1952 sec. 8) of p[0..n).  `tab` is 2048 words (8 KB) of LDS scratch: eight 256-entry tables
 // (slicing by 8: table k advances the register over a byte that lies k bytes further on).  A lane runs over its chunk
 // with aligned 16-byte loads, eight bytes per dependent step; the chunks' registers are then combined across lanes.
-__device__ inline uint32_t wave_crc32(uint32_t *tab, const uint8_t *p, uint32_t n, uint32_t seed = 0)
+// Out of line (three call sites in the inflate kernel; inlined it was a fifth of the kernel's code): the table pointer carries its
+// address space, so its accesses stay LDS accesses.
+__device__ static __attribute__((noinline)) uint32_t wave_crc32(LDS_AS uint32_t *tab, const uint8_t *p_, uint32_t n, uint32_t seed = 0)
 {
     const uint32_t lane = lane_id();
+    const GAS uint8_t *const p = (const GAS uint8_t *)p_;
     WSYNC();
     for (uint32_t i = lane; i < 256; i += 64) {
         uint32_t c = i;
@@ -71,7 +74,8 @@ __device__ inline uint32_t wave_crc32(uint32_t *tab, const uint8_t *p, uint32_t 
     }
     // 16 bytes per load, two steps of eight bytes
     for (; k + 16 <= end; k += 16) {
-        const uint4 d = *(const uint4 *)(p + k);
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ d = *(const GAS u32x4_ *)(p + k);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const uint32_t lo = (h ? d.z : d.x) ^ c, hi = h ? d.w : d.y;
