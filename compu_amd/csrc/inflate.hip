@@ -114,38 +114,41 @@ __device__ __forceinline__ uint32_t make_dist16(uint32_t sym, uint32_t len)
     return len | (((sym >> 1) - 1) << 4) | ((2 + (sym & 1)) << 8);
 }
 
-// ---- geometry of the rolling walk --------------------------------------------------------------------
-// The input bits of a walk round lie in a ring in LDS (window) next to a ring of the same shape that holds one mark bit
-// per input bit (boundaries the segments' owners have passed).  Rings are RING_CHUNKS chunks of 64 dwords (= 8 segments
-// of S_BITS = 256 bits); a chunk is loaded (and its marks cleared) once no running lane is in front of the chunk that
-// it replaces.  A round ends with the block, after PMAX segments, or when a lane's scratch row is full.
-#ifndef CHIP_RING_CHUNKS  // geometry overridable for experiments
-#define CHIP_RING_CHUNKS 12
+// ---- geometry of the speculative wave-parallel walk --------------------------------------------------
+// Per super-round lane i walks the token chain that starts at B + i*S_BITS (a guess, except for lane 0), marks the token
+// boundaries it passes inside its own segment in a bit map of the staged input (one mark bit per input bit), and keeps walking
+// past its segment until it steps on a boundary marked by the owner of the segment it is in (from there on the two chains are
+// the same), at most XT_BITS further.  Every lane records up to ROW_TOKENS tokens.  S_BITS is an odd number of dwords so that
+// the 64 lanes' first window reads hit distinct LDS banks.
+#ifndef CHIP_S_BITS  // geometry overridable for experiments
+#define CHIP_S_BITS 384
+#define CHIP_XT_BITS 1024
+#define CHIP_XT_BITS_FIXED 2048  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
+#define CHIP_ROW_TOKENS 256
 #endif
-constexpr uint32_t S_BITS = 256, S_SHIFT = 8;
-constexpr uint32_t RING_CHUNKS = CHIP_RING_CHUNKS;
-constexpr uint32_t RING_DW = 64 * RING_CHUNKS;
-constexpr uint32_t RING_BYTES = 4 * RING_DW;
-#ifndef CHIP_PMAX
-#define CHIP_PMAX 768
-#define CHIP_ROW_TOKENS 640
+constexpr uint32_t S_BITS = CHIP_S_BITS;
+constexpr uint32_t XT_BITS = CHIP_XT_BITS;
+#ifndef CHIP_XT_BITS_FIXED
+#define CHIP_XT_BITS_FIXED CHIP_XT_BITS
 #endif
-constexpr uint32_t PMAX = CHIP_PMAX;         // segments (= pieces of the token stream) per walk round
-constexpr uint32_t PIECE_ITERS = PMAX / 64;
-constexpr uint32_t ROW_TOKENS = CHIP_ROW_TOKENS;   // tokens a lane can record per walk round
-#ifndef CHIP_TRIP
-#define CHIP_TRIP 8
-#endif
-constexpr uint32_t TRIP = CHIP_TRIP;           // tokens per lane between two maintenance steps (claims, window, records)
-static_assert(PMAX % 64 == 0 && PMAX <= 1024 && ROW_TOKENS % 4 == 0 && 8u * ROW_TOKENS * 7u + 28u < 65536u && TRIP % 4 == 0, "geometry");
-#ifndef CHIP_XT_BITS
-#define CHIP_XT_BITS 2048
-#endif
-constexpr uint32_t XT_BITS = CHIP_XT_BITS;  // how far past its own segment a chain may run before it is cut
+constexpr uint32_t XT_BITS_FIXED = CHIP_XT_BITS_FIXED;
+constexpr uint32_t ROW_TOKENS = CHIP_ROW_TOKENS;
+static_assert(S_BITS % 32 == 0 && ROW_TOKENS % 4 == 0 && 64 * ROW_TOKENS < 65536, "geometry");
+constexpr uint32_t SEG_WORDS = S_BITS / 32 + 1;  // mark words a segment can touch
+// x / S_BITS for x < 2^15 (bit offsets inside a super-round) as a multiply and a shift
+constexpr uint32_t SEG_SHIFT = 22;
+constexpr uint32_t SEG_MAGIC = ((1u << SEG_SHIFT) + S_BITS - 1) / S_BITS;
+constexpr bool seg_magic_ok()
+{
+    for (uint32_t x = 0; x < 64u * S_BITS + 4096u; x++)
+        if (((x * SEG_MAGIC) >> SEG_SHIFT) != x / S_BITS) return false;
+    return true;
+}
+static_assert(seg_magic_ok() && (64u * S_BITS + 4096u) * (uint64_t)SEG_MAGIC < (1ull << 32), "segment index by multiplication");
+constexpr uint32_t WIN_DW = (31 + 64 * S_BITS + 48 + 96 + 31) / 32 + 3;  // staged input of a super-round, dwords
 constexpr uint32_t HDR_IN_DW = 192;    // input window of the block-header parser, dwords (the code lengths take <= 4584 bits)
 
-// Scratch of a wave in HBM: the lanes' token rows, then one record per piece, then the list of pieces on the true path.
-// Layout of the rows: a 128-byte line holds four tokens (one 16-byte store) of each of eight neighbouring lanes, so that one
+// Scratch of a wave in HBM: the lanes' token rows.  Layout: a 128-byte line holds four tokens (one 16-byte store) of each of eight neighbouring lanes, so that one
 // store instruction of the walk fills whole lines (lane l, row token k = 4q + j -> word rowbase(l) + 32 q + j with
 // rowbase(l) = (l / 8) * 8 * ROW_TOKENS + (l % 8) * 4).
 constexpr size_t ROWS_WORDS = (size_t)64 * ROW_TOKENS;
@@ -154,9 +157,6 @@ __device__ __forceinline__ uint32_t row_word(uint32_t k) { return k + (k >> 2) *
 
 // token: [8:0] literal byte, or match length 3..258; [9] match; [25:10] match distance - 1; [31:26] bits the token took in the
 // stream (the walk's flush preparation finds a piece's entry token by adding these up)
-// piece record (two words): .x = bit position the chain stopped at; .y = [5:0] lane, [15:6] first row token, [25:16] tokens, [28:26] reason
-enum : uint32_t { R_RUN = 0, R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
-enum : uint32_t { LK_FAR = 251, LK_EOB = 252, LK_END = 253 };  // link[]: joined a piece more than 250 further on; end-of-block code; any other end
 
 struct HuffMeta {
     uint32_t limit15[16];  // [l] = end (exclusive) of the 15-bit-aligned code space of lengths <= l; [0] = 0
@@ -178,16 +178,18 @@ constexpr uint32_t IMG_WORDS = CHUNK_BYTES / 4 + 8;  // + room for the 16-byte r
 constexpr uint32_t TOK_RING = 4;   // token groups on their way from the scratch rows into LDS (LDS-DMA: no registers held)
 static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0 && IMG_WORDS % 2 == 0, "geometry");
 
-constexpr uint32_t PHASE_BYTES = 4 * (RING_DW + 2) + 4 * RING_DW;  // the walk's two rings are the largest phase
-constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - 128 - PHASE_BYTES) / 4;
+constexpr uint32_t FLUSH_BYTES = 4 * (IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING + 128);
+constexpr uint32_t SERIAL_BYTES = 2 * 288 + 2 * 32 + 2 * sizeof(HuffMeta);  // what the serial fallback keeps behind the flush's state
+constexpr uint32_t PHASE_BYTES = 8 * WIN_DW > FLUSH_BYTES + SERIAL_BYTES ? 8 * WIN_DW : FLUSH_BYTES + SERIAL_BYTES;
+constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - PHASE_BYTES) / 4;
 constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;
 
 struct alignas(16) WaveLds {
     union {  // first: the walk's window reads (ds_read2_b32) take small offsets only
         struct {                             // walk
-            uint32_t win[RING_DW + 2];       // input dwords; two more repeat win[0..1] (a lane reads three dwords from any ring index)
-            uint32_t bm[RING_DW];            // mark bits
-        } ring;
+            uint32_t win[WIN_DW];            // input dwords from the super-round's first on
+            uint32_t bm[WIN_DW];             // mark bits, one per input bit
+        } w;
         struct {                             // block header and table build; sorted[] and the descriptions stay for the (slow) fallback
             uint32_t inbuf[HDR_IN_DW];
             uint32_t cl_lut[1 << CL_ROOT];
@@ -200,10 +202,6 @@ struct alignas(16) WaveLds {
             uint16_t dist_sorted[32];
             HuffMeta lit_h, dist_h;
         } hdr;
-        struct {                             // path resolve
-            uint16_t nxt[PMAX];
-            uint32_t on[PMAX / 32];
-        } res;
         struct {                             // LZ77 execution
             uint32_t out[IMG_WORDS];         // the chunk's output bytes by offset (offset 0 = the dword-aligned address below the chunk)
             uint2 mq[MQ_CAP];                // queued match: .x offset of its first output byte, .y length | distance << 16
@@ -215,11 +213,9 @@ struct alignas(16) WaveLds {
     uint16_t lit_root[1 << LIT_ROOT];
     uint16_t dist_root[1 << DIST_ROOT];
     uint32_t pool[POOL_WORDS];  // literal/length finals and sub-tables from the bottom, distance sub-tables (16-bit) from the top
-    uint8_t link[128];  // of the last 128 pieces claimed (index mod 128): 0 running; 1..250 joined the piece that many further on; LK_* how else it ended
 };
 static_assert(sizeof(WaveLds) <= 10240, "16 waves per CU: LDS is granted in 1280-byte steps");
 static_assert(offsetof(WaveLds, hdr.lit_sorted) >= offsetof(WaveLds, fl.pk) + 512, "the fallback's tables survive the flush");
-static_assert(PMAX * 2 + PMAX / 8 <= PHASE_BYTES, "resolve state");
 // the CRC-32 tables (2048 words) take the whole structure: nothing else is live while a checksum runs
 static_assert(sizeof(WaveLds) >= 2048 * 4, "wave_crc32 needs 8 KB");
 
@@ -925,308 +921,107 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         fresh = true;
     }
 }
-// ---- the rolling walk ----------------------------------------------------------------------------------
-// unsigned minimum over the wave
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ uint32_t dpp_or_ones(uint32_t v)
+// ---- the walk of a super-round -----------------------------------------------------------------------------
+constexpr size_t SCRATCH_WORDS = ROWS_WORDS;
+
+// lane i's value of x from lane `src` (any lane; ds_bpermute: no LDS memory is touched)
+__device__ __forceinline__ uint32_t lane_gather(uint32_t x, uint32_t src)
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
-{
-    uint32_t t;
-    t = dpp_or_ones<0x111>(v); v = v < t ? v : t;
-    t = dpp_or_ones<0x112>(v); v = v < t ? v : t;
-    t = dpp_or_ones<0x114>(v); v = v < t ? v : t;
-    t = dpp_or_ones<0x118>(v); v = v < t ? v : t;
-    t = dpp_or_ones<0x142, 0xa>(v); v = v < t ? v : t;
-    t = dpp_or_ones<0x143, 0xc>(v); v = v < t ? v : t;
-    return rdlane(v, 63);
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
 }
 
-// the wave's scratch in HBM
-struct Scratch {
-    uint32_t *rows;   // token rows
-    uint2 *rec;       // [PMAX] piece records
-    uint32_t *path;   // [PMAX] two words per non-empty piece of the true path, in stream order (the flush's piece descriptions)
-    uint32_t *marks;  // [8 * PMAX + 64] the round's mark bits (spilled from the ring as its chunks are replaced)
-    uint32_t *dump;   // [256] where a lane that took no token in a group of four puts the group (the walk counts its stores)
-};
-constexpr size_t SCRATCH_WORDS = ROWS_WORDS + 2 * PMAX + 2 * PMAX + 8 * PMAX + 64 + 256;
+// why a lane's chain ended
+enum : uint32_t { R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
 
-constexpr uint32_t NONE = 0xffffffffu;
-
-// One round of the walk: decodes from the true token boundary G on, over at most PMAX segments of the grid that starts at
-// G's dword.  Tokens go to rows, a record per segment ("piece") to sc.rec, the mark bits to sc.marks.  Returns the number of
-// pieces claimed.
-__device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const uint32_t G_, const uint32_t end_bit_, const Scratch &sc STAT_PARAM)
+// One super-round: stages the input from the true token boundary B on, walks 64 chains, finds the true stream among them and
+// leaves its description in L.fl.pk (ntok tokens in npieces pieces).  term_why / term_pos say how and where the stream ends.
+__device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const uint32_t B_, const uint32_t end_bit_, uint32_t *rows_, const uint32_t xt_bits,
+                                             uint32_t &ntok_out, uint32_t &term_why, uint32_t &term_pos STAT_PARAM)
 {
     const uint32_t lane = lane_id();
-    const uint32_t G = rdfirst(G_), end_bit = rdfirst(end_bit_);
+    const uint32_t B = rdfirst(B_), end_bit = rdfirst(end_bit_);
     GAS const uint32_t *const g32 = rdfirst_gptr(w.g32);
     const uint32_t total_dw = rdfirst(w.total_dw);
-    GAS uint32_t *const myrow = rdfirst_gptr(sc.rows) + row_base(lane);
-    GAS u32x2 *const recg = (GAS u32x2 *)rdfirst_gptr(sc.rec);
-    GAS uint32_t *const marks = rdfirst_gptr(sc.marks);
+    GAS uint32_t *const myrow = rdfirst_gptr(rows_) + row_base(lane);
     uint16_t *const pool16 = (uint16_t *)L.pool;
-    const uint32_t D0 = G >> 5;                 // the grid's first dword: segment k = dwords D0 + 8 k .. D0 + 8 k + 7
-    const uint32_t gbit = D0 << 5;
-    uint32_t nseg_end = (end_bit - gbit + S_BITS - 1) >> S_SHIFT;  // segments that start in front of the input's end
-    nseg_end = nseg_end < PMAX ? nseg_end : PMAX;
-    // chunks (64 dwords) the round can need: its segments plus what a token that starts in the last one may read
-    uint32_t cmax = (8u * nseg_end + 11u + 63u) >> 6;
+    const uint32_t D0 = B >> 5, base4 = 4u * D0;
+    WSYNC();  // the phase before (header parse, previous flush) is done with the window's place
     {
-        const uint32_t cin = ((end_bit + 31u) >> 5) - D0 + 3u;  // ... but nothing behind the input's end
-        const uint32_t c2 = (cin + 63u) >> 6;
-        cmax = cmax < c2 ? cmax : c2;
-    }
-    auto chunk_word = [&](uint32_t c) -> uint32_t {
-        const uint32_t i = D0 + 64u * c + lane;
-        return i < total_dw ? g32[i] : 0u;
-    };
-    WSYNC();  // the phase before (header parse, previous flush) is done with the rings' place
-    L.link[lane] = 0;
-    L.link[64u + lane] = 0;
-    // the first chunks: all loads go out before the first LDS store waits for one
-    uint32_t cload = cmax < RING_CHUNKS ? cmax : RING_CHUNKS;
-    {
-        uint32_t v[RING_CHUNKS];
+        // all loads of the window go out before the first LDS store waits for one
+        constexpr uint32_t PER_LANE = (WIN_DW + 63) / 64;
+        uint32_t v[PER_LANE];
 #pragma unroll
-        for (uint32_t c = 0; c < RING_CHUNKS; c++) v[c] = c < cload ? chunk_word(c) : 0u;
-#pragma unroll
-        for (uint32_t c = 0; c < RING_CHUNKS; c++) {
-            L.ring.win[64u * c + lane] = v[c];
-            L.ring.bm[64u * c + lane] = 0;
+        for (uint32_t j = 0; j < PER_LANE; j++) {
+            const uint32_t i = D0 + 64u * j + lane;
+            v[j] = i < total_dw ? g32[i] : 0u;
         }
-        if (lane < 2) L.ring.win[RING_DW + lane] = v[0];
+#pragma unroll
+        for (uint32_t j = 0; j < PER_LANE; j++) {
+            const uint32_t k = 64u * j + lane;
+            if (k < WIN_DW) {
+                L.w.win[k] = v[j];
+                L.w.bm[k] = 0;
+            }
+        }
     }
-    uint32_t slot = cload == RING_CHUNKS ? 0u : cload;  // ring slot of chunk cload
-    uint32_t cissued = cload;  // chunks asked for (the ring's later chunks arrive by LDS-DMA: no register holds a load in flight)
-    bool padfix = false;
-    const uint32_t win_lds = rdfirst((uint32_t)(uintptr_t)(LDS_AS uint32_t *)L.ring.win);
-    GAS uint32_t *const mydump = rdfirst_gptr(sc.dump) + 4u * lane;
     LSYNC();
     STAT_ACC(1);
     STAT_ADD(8, 1);
-
-    // per-lane state
-    uint32_t seg = NONE, p = 0, own_end = 0, nst = 0, rowstart = 0, rowpos = 0, stop = R_RUN;
-    uint32_t pg = 0, ng = 0;           // position and count at the start of the running group of four tokens
-    uint32_t jb = 0, z = 0, pn = 0;    // of the lane's last token: join bit, halt flags, end position
-    bool stopped = false;              // the lane's last token was not taken
-    // wave state
-    uint32_t next_seg = 0, dl = 0, epoch = 0, T = 0;
-    bool draining = false, pend = false, lost = false;
-    for (;;) {
-        // ======== maintenance: blocked lanes, finished pieces, window, claims ========
-        STAT_ACC(15);
-        if (cissued != cload) {
-            // The chunks asked for in the step before have landed once at most the trip's token stores (TRIP / 4 of them, always
-            // issued) are outstanding: vector memory operations complete in order.
-            static_assert(TRIP / 4 == 2, "the wait below counts the trip's stores");
-            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            if (padfix && lane < 2) L.ring.win[RING_DW + lane] = L.ring.win[lane];
-            padfix = false;
-            cload = cissued;
+    // ---- walk: every lane decodes from its guessed start until it joins another lane's chain ----
+    const uint32_t s0 = B + lane * S_BITS;
+    const uint32_t own_end = s0 + S_BITS;
+    uint32_t hard = own_end + xt_bits;  // a token is taken if it ends in front of this: the chain's limit, the input's end
+    {
+        const uint32_t sr_end = B + 64u * S_BITS;  // nobody to join behind the last segment
+        hard = hard < sr_end ? hard : sr_end;
+        hard = hard < end_bit ? hard : end_bit;
+    }
+    uint32_t p = s0, nst = 0;
+    uint32_t jb = 0, z = 0, pn = s0;  // of the lane's last token: join bit, halt flags, end position
+    bool run = s0 < end_bit;
+    // A token's work is straight-line code; a lane whose token cannot be taken (it joined another chain, met an end-of-block or
+    // invalid code, or the token ends behind `hard`) drops out with jb / z / pn as that step left them: the reason is read off them
+    // after the loop.
+    auto token = [&](uint32_t &tok) -> bool {
+        const uint32_t a = ((p >> 3) & ~3u) - base4;
+        const uint32_t bit = 1u << (p & 31u);
+        const uint32_t mine = p < own_end ? bit : 0u;
+        const uint32_t old = atomicOr((uint32_t *)((uint8_t *)L.w.bm + a), mine);
+        jb = old & (bit - mine);  // a boundary of the segment's owner: from here on the two chains are one
+        const uint32_t *wp = (const uint32_t *)((const uint8_t *)L.w.win + a);
+        const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
+        const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, p), hi = __builtin_amdgcn_alignbit(d2, d1, p);
+        const uint32_t r = L.lit_root[lo & ((1u << LIT_ROOT) - 1u)];
+        const uint32_t e = L.pool[(r >> 5) + __builtin_amdgcn_ubfe(lo, LIT_ROOT, r)];
+        const uint32_t n1 = __builtin_amdgcn_ubfe(e, 10, 5);
+        const uint32_t msk = (uint32_t)((int32_t)e >> 31);  // all ones for a length code
+        const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+        uint32_t m = L.dist_root[w2 & ((1u << DIST_ROOT) - 1u)] & msk;
+        if (m & D_LONG) {  // a distance code of more than 8 bits (1 % of the matches): through its sub-table
+            const uint32_t b16 = ((m >> 4) & 127u) | ((m >> 12) << 7);
+            m = pool16[b16 + __builtin_amdgcn_ubfe(w2, DIST_ROOT, m)];
         }
-        const uint32_t F = gbit + (next_seg << S_SHIFT);  // first bit nobody has claimed
-        bool held = seg != NONE;
-        if (stopped) {  // why the lane's last token was not taken, in zlib's order of verdicts
-            if (jb) stop = R_JOIN;
-            else if (pn > end_bit) stop = R_NEED_INPUT;  // the token does not end inside the input: the chain ends here, whatever comes
-            else if (z) stop = z == F_HALT ? (uint32_t)R_EOB : (uint32_t)R_BAD;
-            else {
-                p = pg;  // the window was not there yet: again from the group's start (a group's tokens are stored together)
-                nst = ng;
-            }
-        }
-        stopped = false;
-        if (held && stop == R_RUN) {
-            if (draining && p >= F) stop = R_LIMIT;  // nobody will mark a boundary out there any more
-            if (rowstart + nst + TRIP + 4u > ROW_TOKENS) stop = R_LIMIT;  // the lane's row is full
-            // a chain that has run XT_BITS past its segment without meeting another holds the ring's oldest chunks, and with them every
-            // claim (fixed-Huffman data with runs of one byte keeps two parses apart for ever): cut it; if it carried the true stream the
-            // round ends there and the next one starts on it
-            if (p - own_end > XT_BITS && p > own_end) stop = R_LIMIT;
-        }
-        bool fin = held && stop != R_RUN;
-        bool ended = false;  // the true stream has ended (end of block, invalid code, input exhausted, a chain cut short)
-        if (__any(fin)) {
-            const uint32_t jd = ((p - gbit) >> S_SHIFT) - seg;
-            const uint32_t code = stop == R_JOIN ? (jd < LK_FAR ? jd : (uint32_t)LK_FAR) : stop == R_EOB ? (uint32_t)LK_EOB : (uint32_t)LK_END;
-            if (fin && next_seg - seg <= 128u) L.link[seg & 127u] = (uint8_t)code;  // (an older piece's place has gone to a newer one)
-            const uint64_t endm = __ballot(fin && stop != R_JOIN);
-            if (endm && !lost) pend = true;  // such an end counts if it lies on the true stream: find out below
-            if (fin) {
-                recg[seg] = u32x2{p, lane | (rowstart << 6) | (nst << 16) | (stop << 26)};
-                rowpos = (rowstart + nst + 3u) & ~3u;
-                seg = NONE;
-                stop = R_RUN;
-            }
-            LSYNC();
-        }
-        STAT_ACC(12);
-        // ---- the true stream's piece: piece T carries it as far as is known.  Follow the links of finished pieces from T (pointer
-        // doubling over the 128 pieces from T on, two per lane, links fetched with ds_bpermute) when a chain has ended somewhere
-        // in front, or before the pieces' places in link[] run out.
-        while (!lost && (pend || next_seg - T > 96u)) {
-            const uint32_t k0 = T + lane, k1 = T + 64u + lane;
-            const uint32_t v0 = k0 < next_seg ? L.link[k0 & 127u] : 0u, v1 = k1 < next_seg ? L.link[k1 & 127u] : 0u;
-            uint32_t l0 = (v0 - 1u < 250u && lane + v0 < 128u) ? lane + v0 : lane;
-            uint32_t l1 = (v1 - 1u < 250u && 64u + lane + v1 < 128u) ? 64u + lane + v1 : 64u + lane;
-#pragma unroll
-            for (int r = 0; r < 7; r++) {
-                const uint32_t a0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l0 << 2), (int)l0), b0 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l0 << 2), (int)l1);
-                const uint32_t a1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l1 << 2), (int)l0), b1 = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(l1 << 2), (int)l1);
-                l0 = l0 < 64u ? a0 : b0;
-                l1 = l1 < 64u ? a1 : b1;
-            }
-            const uint32_t Tn = T + rdlane(l0, 0);  // the last piece the links lead to
-            const uint32_t ti = Tn - T;
-            const uint32_t c = ti < 64u ? rdlane(v0, ti & 63u) : rdlane(v1, ti & 63u);  // how it ended, if it has
-            const bool moved = Tn != T;
-            T = Tn;
-            if (c >= LK_EOB) {
-                ended = true;
-                break;
-            }
-            if (c == LK_FAR) {  // (a chain that ran over more than 250 segments: not followed; the round then runs its full length)
-                lost = true;
-                pend = false;
-                break;
-            }
-            // ends in front of T are still open; those behind it are not on the stream
-            pend = __any((v0 >= LK_EOB && k0 > T) || (v1 >= LK_EOB && k1 > T));
-            if (c == 0 || !moved) break;  // T is running (or its link leads out of the window: next time)
-        }
-        if (ended) {  // nothing behind that end is of use: the round is over
-            held = seg != NONE;
-            if (held) {
-                recg[seg] = u32x2{p, lane | (rowstart << 6) | (nst << 16) | (R_LIMIT << 26)};
-                seg = NONE;
-            }
-            STAT_ADD(22, 1);
-            break;
-        }
-        STAT_ACC(14);
-        held = seg != NONE;
-        // ---- window: up to two chunks per step are asked for, each replacing the ring's oldest once no lane is in front of its end;
-        // they count as loaded from the next maintenance step on
-        {
-            dl = wave_min_u32(held ? (p >> 5) - D0 : 8u * next_seg);  // lowest dword (from D0) a lane may still touch
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                if (cissued < cmax && dl >= 64u * (cissued - RING_CHUNKS + 1u)) {
-                    const uint32_t old = L.ring.bm[64u * slot + lane];
-                    marks[64u * (cissued - RING_CHUNKS) + lane] = old;  // the marks of the chunk that leaves the ring
-                    L.ring.bm[64u * slot + lane] = 0;
-                    const uint32_t i = D0 + 64u * cissued + lane;
-                    if (i < total_dw) {  // (dwords behind the input keep what the slot held: no token can use them)
-                        const GAS uint32_t *src = g32 + i;
-                        const uint32_t dst = win_lds + 256u * slot;
-                        uint32_t keep;
-                        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                                     : "=&s"(keep)
-                                     : "v"(src), "s"(dst)
-                                     : "memory");
-                    }
-                    if (slot == 0) padfix = true;
-                    cissued++;
-                    slot = slot + 1u == RING_CHUNKS ? 0u : slot + 1u;
-                }
-            }
-            LSYNC();
-        }
-        // a token may be taken if it ends in front of `hard`: the input's end, and what the ring holds (a lane reads three
-        // dwords from its position on)
-        const uint32_t avail = ((D0 + 64u * cload) << 5) - 96u;  // (once the input's last dword is in, this lies behind end_bit)
-        const uint32_t hard = end_bit < avail ? end_bit : avail;
-        // ---- claims: idle lanes take the next segments in lane order
-        {
-            const bool want = !held && rowpos + 64u <= ROW_TOKENS;
-            if (__any(!held && !want)) draining = true;  // a full row: let the round end (the next one starts with empty rows)
-            uint32_t lim = next_seg;
-            if (!draining) {
-                lim = nseg_end;
-                if (cload < cmax) {
-                    const uint32_t lw = 8u * cload - 1u;  // segment k reads up to dword 8 k + 10
-                    lim = lim < lw ? lim : lw;
-                }
-                const uint32_t lt = lost ? 0xffffffffu : T + 128u;  // a piece has a place in link[] until the piece 128 further on is claimed
-                lim = lim < lt ? lim : lt;
-                if (pend) lim = next_seg;  // a chain has ended in front of the true stream: no new pieces until it is known whether it counts
-            }
-            const uint64_t fm = __ballot(want);
-            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-            const uint32_t k = next_seg + rank;
-            if (want && k < lim) {
-                seg = k;
-                p = k == 0 ? G : gbit + (k << S_SHIFT);
-                own_end = gbit + ((k + 1u) << S_SHIFT);
-                rowstart = rowpos;
-                nst = 0;
-                L.link[k & 127u] = 0;
-            }
-            const uint32_t nfree = (uint32_t)__popcll(fm), room = lim > next_seg ? lim - next_seg : 0u;
-            const uint32_t ncl = nfree < room ? nfree : room;
-            next_seg += ncl;
-            STAT_ADD(19, ncl);
-            if (next_seg >= nseg_end) draining = true;
-        }
-        bool run = seg != NONE;
-        if (!__any(run)) {
-            if (draining) break;
-            continue;  // waiting for the window (cannot last: an idle wave's chunks are always replaceable)
-        }
-        // ring address of a position: byte offset of its dword from the first dword of the oldest ring epoch a lane can be in (dl,
-        // found before the claims, is still the lowest dword in use: a claimed segment starts where dl's idle lanes put it)
-        while (dl >= epoch + RING_DW) epoch += RING_DW;
-        const uint32_t base4 = 4u * (D0 + epoch);
+        const uint32_t cl2 = m & 15u, eb2 = __builtin_amdgcn_ubfe(m, 4, 4);
+        const uint32_t dm1 = (__builtin_amdgcn_ubfe(m, 8, 2) << eb2) + __builtin_amdgcn_ubfe(w2, cl2, eb2);
+        z = (e & (F_HALT | F_INV)) | (m & D_BAD);
+        pn = p + n1 + cl2 + eb2;
+        if ((jb | z) != 0 || pn > hard) return false;
+        const uint32_t v = __builtin_amdgcn_ubfe(lo, e, e >> 5) + __builtin_amdgcn_ubfe(e, 16, 9);
+        tok = (((dm1 << 10) | 512u) & msk) | v;
+        p = pn;
+        nst++;
+        return true;
+    };
+    bool full = false;  // the lane's row is full
+    while (__any(run)) {
         STAT_ADD(11, 1);
-        STAT_ACC(13);
-        // ======== a trip: TRIP tokens per running lane ========
-        // A token's work is straight-line code; a lane whose token cannot be taken (it joined another chain, met an end-of-block or
-        // invalid code, or the token ends behind `hard`) drops out of the trip with jb / z / pn as that step left them: the next
-        // maintenance step reads the reason off them.
-        auto token = [&](uint32_t &tok) -> bool {
-            const uint32_t x = ((p >> 3) & ~3u) - base4;
-            const uint32_t xw = x - RING_BYTES;
-            const uint32_t a = x < xw ? x : xw;  // x mod RING_BYTES (x < 2 RING_BYTES)
-            const uint32_t bit = 1u << (p & 31u);
-            const uint32_t mine = p < own_end ? bit : 0u;
-            const uint32_t old = atomicOr((uint32_t *)((uint8_t *)L.ring.bm + a), mine);
-            jb = old & (bit - mine);  // a boundary of the segment's owner: from here on the two chains are one
-            const uint32_t *wp = (const uint32_t *)((const uint8_t *)L.ring.win + a);
-            const uint32_t d0 = wp[0], d1 = wp[1], d2 = wp[2];
-            const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, p), hi = __builtin_amdgcn_alignbit(d2, d1, p);
-            const uint32_t r = L.lit_root[lo & ((1u << LIT_ROOT) - 1u)];
-            const uint32_t e = L.pool[(r >> 5) + __builtin_amdgcn_ubfe(lo, LIT_ROOT, r)];
-            const uint32_t n1 = __builtin_amdgcn_ubfe(e, 10, 5);
-            const uint32_t msk = (uint32_t)((int32_t)e >> 31);  // all ones for a length code
-            const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-            uint32_t m = L.dist_root[w2 & ((1u << DIST_ROOT) - 1u)] & msk;
-            if (m & D_LONG) {  // a distance code of more than 8 bits (1 % of the matches): through its sub-table
-                const uint32_t b16 = ((m >> 4) & 127u) | ((m >> 12) << 7);
-                m = pool16[b16 + __builtin_amdgcn_ubfe(w2, DIST_ROOT, m)];
-            }
-            const uint32_t cl2 = m & 15u, eb2 = __builtin_amdgcn_ubfe(m, 4, 4);
-            const uint32_t dm1 = (__builtin_amdgcn_ubfe(m, 8, 2) << eb2) + __builtin_amdgcn_ubfe(w2, cl2, eb2);
-            z = (e & (F_HALT | F_INV)) | (m & D_BAD);
-            pn = p + n1 + cl2 + eb2;
-            if ((jb | z) != 0 || pn > hard) return false;
-            const uint32_t v = __builtin_amdgcn_ubfe(lo, e, e >> 5) + __builtin_amdgcn_ubfe(e, 16, 9);
-            tok = (((dm1 << 10) | 512u) & msk) | v;
-            p = pn;
-            nst++;
-            return true;
-        };
-#pragma unroll
-        for (uint32_t gq = 0; gq < TRIP / 4; gq++) {
-            uint32_t t4[4] = {0, 0, 0, 0};
-            const bool ran = run;
-            if (run) {
-                pg = p;
-                ng = nst;
+        uint32_t t4[4] = {0, 0, 0, 0};
+        const uint32_t ng = nst;
+        if (run) {
+            if (nst + 4u > ROW_TOKENS) {
+                run = false;
+                full = true;
+            } else {
                 bool ok = token(t4[0]);
                 if (ok) {
                     ok = token(t4[1]);
@@ -1237,184 +1032,97 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
                 }
                 run = ok;
             }
-            // (always issued: the maintenance step's wait for the window chunks counts these stores)
-            *(GAS u32x4 *)((ran && nst > ng) ? myrow + 8u * (rowstart + ng) : mydump) = u32x4{t4[0], t4[1], t4[2], t4[3]};
-            STAT_ADD(21, __popcll(__ballot(ran)));
         }
-        stopped = seg != NONE && !run;
+        if (nst > ng) *(GAS u32x4 *)(myrow + 8u * ng) = u32x4{t4[0], t4[1], t4[2], t4[3]};  // ng is a multiple of 4: row_word(ng)
     }
-    // the marks still in the ring
+    // why the lane's last token was not taken, in zlib's order of verdicts
+    uint32_t why = R_LIMIT;  // the chain simply ends (limit reached, row full, or it never ran)
+    if (s0 < end_bit && !full) {
+        if (jb) why = R_JOIN;
+        else if (pn > end_bit) why = R_NEED_INPUT;  // the token does not end inside the input
+        else if (z) why = z == F_HALT ? (uint32_t)R_EOB : (uint32_t)R_BAD;
+    }
+    STAT_ADD(21, __popcll(__ballot(nst != 0)));
+    STAT_ACC(2);
+    // ---- the true stream: lane 0's chain, then the chain it joined from the join on, and so on ----
+    // the lane a chain joined, and the index, in that lane's row, of the token that starts at the join: the boundaries the
+    // segment's owner marked in front of it
+    const uint32_t rel = p - B;
+    const uint32_t jl = why == R_JOIN ? (__umul24(rel, SEG_MAGIC) >> SEG_SHIFT) & 63u : lane;
+    uint32_t a_join = 0;
+    if (__any(why == R_JOIN)) {
+        const uint32_t sj = B + jl * S_BITS;            // the owner's first bit
+        const uint32_t w0 = (sj >> 5) - D0;             // ... and its dword in the window
+        const uint32_t lo_cut = sj & 31u;               // bits below this in the first word belong to the segment before
+        const uint32_t nb = p - (sj & ~31u);            // marks in front of bit nb (counted from the first word's bit 0) count
+#pragma unroll
+        for (uint32_t t = 0; t < SEG_WORDS; t++) {
+            uint32_t mw = L.w.bm[w0 + t];
+            if (t == 0) mw &= ~0u << lo_cut;
+            const int32_t k = (int32_t)nb - 32 * (int32_t)t;
+            const uint32_t keep = k <= 0 ? 0u : k >= 32 ? 0xffffffffu : (1u << k) - 1u;
+            a_join += __popc(mw & keep);
+        }
+        if (why != R_JOIN) a_join = 0;
+    }
+    // the n-th piece of the stream = the lane reached from lane 0 by n joins: powers of the join map by doubling, composed along
+    // the bits of n (lanes: ds_bpermute, no memory); the map's fixed points are the chains that end the stream
+    uint32_t node = 0;  // lane n: the lane holding the stream's n-th piece
     {
-        const uint32_t first = cload > RING_CHUNKS ? cload - RING_CHUNKS : 0u;
-        uint32_t s = cload > RING_CHUNKS ? slot : 0u;  // the oldest chunk's slot
-        for (uint32_t c = first; c < cload; c++) {
-            marks[64u * c + lane] = L.ring.bm[64u * s + lane];
-            s = s + 1u == RING_CHUNKS ? 0u : s + 1u;
+        uint32_t pw = jl;  // the join map to the power 2^r
+#pragma unroll
+        for (int r = 0; r < 6; r++) {
+            const uint32_t nx = lane_gather(pw, node);
+            if ((lane >> r) & 1u) node = nx;
+            pw = lane_gather(pw, pw);
         }
     }
-    return next_seg;
+    const uint32_t prev = wave_shr1(node);                    // the piece before (lane 0: none)
+    const bool fresh = lane == 0 || node != prev;               // lanes behind the stream's end repeat its last piece
+    const uint32_t e_nst = lane_gather(nst, node);
+    const uint32_t g_a0 = lane_gather(a_join, prev);  // (every lane takes part: a lane that is switched off cannot be read)
+    const uint32_t e_a0 = lane == 0 ? 0u : g_a0;      // where the stream enters the piece
+    const uint32_t cnt = (fresh && e_nst > e_a0) ? e_nst - e_a0 : 0u;
+    const uint32_t incl = wave_incl_scan(cnt);
+    const uint64_t nonempty = __ballot(cnt != 0);
+    WSYNC();  // the walk's LDS reads are done (the flush's state takes the window's place)
+    if (cnt) {
+        const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt()), first = incl - cnt;
+        L.fl.pk[2u * k] = first;
+        L.fl.pk[2u * k + 1u] = ((e_a0 - first) & 0xffffu) | (row_base(node) << 16);  // row token = stream index + (a0 - first)
+    }
+#ifdef CHIP_STATS
+    if (st_[8] == 1) {  // debug: the unit's first super-round
+        st_[22] = ((unsigned long long)rdlane(nst, 0) << 48) | ((unsigned long long)rdlane(why, 0) << 40) | ((unsigned long long)(rdlane(p, 0) - B) << 16) | (rdlane(jl, 0) << 8) | rdlane(a_join, 0);
+        st_[23] = ((unsigned long long)rdlane(nst, 1) << 48) | ((unsigned long long)rdlane(why, 1) << 40) | ((unsigned long long)(rdlane(p, 1) - B) << 16) | (rdlane(jl, 1) << 8) | rdlane(a_join, 1);
+        st_[19] = ((unsigned long long)rdlane(node, 1) << 48) | ((unsigned long long)rdlane(node, 2) << 40) | ((unsigned long long)rdlane(cnt, 0) << 24) | ((unsigned long long)rdlane(cnt, 1) << 8) | (B & 31u);
+        st_[6] = ((unsigned long long)rdlane(e_a0, 1) << 32) | rdlane(e_nst, 1);
+        st_[0] = ((unsigned long long)L.w.bm[((B + S_BITS) >> 5) - D0] << 32) | L.w.bm[((B + S_BITS) >> 5) - D0 + 1];
+    }
+#endif
+    const uint32_t kz = rdlane(node, 63);  // the chain the stream ends in
+    term_why = rdlane(why, kz);
+    term_pos = rdlane(p, kz);
+    ntok_out = rdlane(incl, 63u);
+    WSYNC();
+    STAT_ACC(3);
+    STAT_ADD(9, __popcll(nonempty));
+    STAT_ADD(10, ntok_out);
+    return (uint32_t)__popcll(nonempty);
 }
 
-// Follows the chain of joins from piece 0 through the records of the round's P pieces and writes the flush's piece descriptions
-// (two words per non-empty piece of the true path, in stream order) to sc.path.  Returns their number; term_piece / term_why /
-// term_pos describe how the stream ends.
-__device__ CHIP_PHASE_FN uint32_t resolve_path(WaveLds &L, const Scratch &sc, const uint32_t P_, const uint32_t G_, uint32_t &ntok_out, uint32_t &term_why, uint32_t &term_pos STAT_PARAM)
-{
-    const uint32_t lane = lane_id();
-    const uint32_t P = rdfirst(P_), G = rdfirst(G_), gbit = (G >> 5) << 5;
-    GAS const u32x2 *const recg = (GAS const u32x2 *)rdfirst_gptr(sc.rec);
-    GAS uint32_t *const pathg = rdfirst_gptr(sc.path);
-    GAS const uint32_t *const marks = rdfirst_gptr(sc.marks);
-    WSYNC();  // records, tokens and marks have landed; the rings are dead
-    uint32_t q[PIECE_ITERS], info[PIECE_ITERS], nx[PIECE_ITERS];
-    uint8_t *const entry = (uint8_t *)L.phase_words_ + sizeof(L.res);  // offset (bits) inside its segment at which the true stream enters a piece
-#pragma unroll
-    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-        const uint32_t k = 64u * i + lane;
-        q[i] = 0;
-        info[i] = R_LIMIT << 26;
-        nx[i] = k;
-        if (64u * i < P) {  // uniform: a short round costs as many steps as it has pieces
-            u32x2 r = u32x2{0, R_LIMIT << 26};
-            if (k < P) r = recg[k];
-            q[i] = r.x - gbit;
-            info[i] = r.y;
-            nx[i] = (r.y >> 26) == R_JOIN ? q[i] >> S_SHIFT : k;
-            L.res.nxt[k] = (uint16_t)nx[i];
-        }
-    }
-    if (lane < PMAX / 32) L.res.on[lane] = lane == 0 ? 1u : 0u;
-    LSYNC();
-    // pieces on the path from piece 0, by pointer doubling over the join links (links only point forward)
-    const uint32_t rounds = P > 1 ? 32u - (uint32_t)__clz((int)(P - 1u)) : 0u;
-    for (uint32_t r = 0; r < rounds; r++) {
-        uint32_t nn[PIECE_ITERS];
-#pragma unroll
-        for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-            const uint32_t k = 64u * i + lane;
-            nn[i] = 0;
-            if (64u * i < P) {
-                const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
-                if (on && nx[i] != k) atomicOr(&L.res.on[nx[i] >> 5], 1u << (nx[i] & 31u));
-                nn[i] = L.res.nxt[nx[i]];
-            }
-        }
-        LSYNC();
-#pragma unroll
-        for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-            if (64u * i < P) {
-                nx[i] = nn[i];
-                L.res.nxt[64u * i + lane] = (uint16_t)nn[i];
-            }
-        }
-        LSYNC();
-    }
-    // where the stream enters each piece of the path: the position its predecessor joined at
-    if (lane == 0) entry[0] = (uint8_t)(G - gbit);
-    LSYNC();
-#pragma unroll
-    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-        if (64u * i < P) {
-            const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
-            if (on && (info[i] >> 26) == R_JOIN) entry[q[i] >> S_SHIFT] = (uint8_t)(q[i] & (S_BITS - 1u));
-        }
-    }
-    LSYNC();
-    // how the stream ends: the last piece of the path
-    {
-        uint32_t kz = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-            if (64u * i < P) {
-                const uint64_t onm = __ballot((L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u);
-                if (onm) kz = 64u * i + 63u - (uint32_t)__clzll((long long)onm);
-            }
-        }
-        const uint32_t zi = kz >> 6, zl = kz & 63u;
-        uint32_t wq = 0, wi = 0;
-#pragma unroll
-        for (uint32_t i = 0; i < PIECE_ITERS; i++)
-            if (i == zi) {
-                wq = rdlane(q[i], zl);
-                wi = rdlane(info[i], zl);
-            }
-        term_why = wi >> 26;
-        term_pos = wq + gbit;
-    }
-    // a piece's first token on the stream = the boundaries its owner marked in front of the entry (from the spilled marks: the
-    // loads of two pieces per lane are in flight together)
-    uint32_t a0s[PIECE_ITERS];
-#pragma unroll
-    for (uint32_t i0 = 0; i0 < PIECE_ITERS; i0 += 2) {
-        if (64u * i0 >= P) break;
-        u32x4 m[2][2];
-#pragma unroll
-        for (uint32_t j = 0; j < 2; j++) {
-            const uint32_t i = i0 + j, k = 64u * i + lane;
-            const bool on = i < PIECE_ITERS && 64u * i < P && ((L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u);
-            m[j][0] = m[j][1] = u32x4{0, 0, 0, 0};
-            if (on) {
-                m[j][0] = *(GAS const u32x4 *)(marks + 8u * k);
-                m[j][1] = *(GAS const u32x4 *)(marks + 8u * k + 4u);
-            }
-        }
-#pragma unroll
-        for (uint32_t j = 0; j < 2; j++) {
-            const uint32_t i = i0 + j;
-            if (i < PIECE_ITERS) {
-                const uint32_t eo = entry[64u * i + lane];
-                const uint32_t mw[8] = {m[j][0].x, m[j][0].y, m[j][0].z, m[j][0].w, m[j][1].x, m[j][1].y, m[j][1].z, m[j][1].w};
-                uint32_t c = 0;
-#pragma unroll
-                for (uint32_t wd = 0; wd < 8; wd++) {
-                    const int32_t nb = (int32_t)eo - 32 * (int32_t)wd;
-                    const uint32_t msk = nb <= 0 ? 0u : nb >= 32 ? 0xffffffffu : (1u << nb) - 1u;
-                    c += __popc(mw[wd] & msk);
-                }
-                a0s[i] = c;
-            }
-        }
-    }
-    // descriptions in stream order
-    uint32_t npk = 0, ntok = 0;
-#pragma unroll
-    for (uint32_t i = 0; i < PIECE_ITERS; i++) {
-        if (64u * i < P) {  // uniform
-            const bool on = (L.res.on[2u * i + (lane >> 5)] >> (lane & 31u)) & 1u;
-            const uint32_t a0 = a0s[i];
-            const uint32_t nst = (info[i] >> 16) & 1023u;
-            const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
-            const uint32_t incl = wave_incl_scan(cnt);
-            const uint64_t nonempty = __ballot(cnt != 0);
-            if (cnt) {
-                const uint32_t first = ntok + incl - cnt;
-                const uint32_t slot = npk + (uint32_t)__popcll(nonempty & lanemask_lt());
-                const uint32_t rowtok = ((info[i] >> 6) & 1023u) + a0;
-                pathg[2u * slot] = first;
-                pathg[2u * slot + 1u] = ((rowtok - first) & 0xffffu) | (row_base(info[i] & 63u) << 16);
-            }
-            npk += (uint32_t)__popcll(nonempty);
-            ntok += rdlane(incl, 63u);
-        }
-    }
-    ntok_out = ntok;
-    STAT_ADD(9, npk);
-    STAT_ADD(10, ntok);
-    return npk;
-}
-// ---- a block's tokens: walk rounds, path resolve, execution --------------------------------------------
-// Serial stand-in for a walk round, for a block whose tables do not fit pool[] (more than ~600 table entries behind the 9-bit
-// root: possible in theory, not seen): up to 256 tokens, one at a time, every lane doing the same work, codes resolved
+// ---- a block's tokens: super-rounds of walk, path resolve, execution ------------------------------------
+// Serial stand-in for a super-round's walk, for a block whose tables do not fit pool[] (more than ~600 table entries behind the
+// 9-bit root: possible in theory, not seen): up to 192 tokens, one at a time, every lane doing the same work, codes resolved
 // canonically from the sorted symbols that the table build leaves at the end of the header's LDS.  The tokens go to lane 0's
 // row as one piece.  Slow; exists so that every valid stream decodes.
-__device__ CHIP_PHASE_FN uint32_t serial_round(WaveLds &L, InWin &w, uint32_t pos, const uint32_t end_bit, const Scratch &sc, uint32_t &ntok_out,
+__device__ CHIP_PHASE_FN uint32_t serial_round(WaveLds &L, InWin &w, uint32_t pos, const uint32_t end_bit, uint32_t *rows_, uint32_t &ntok_out,
                                                uint32_t &term_why, uint32_t &term_pos)
 {
     const uint32_t lane = lane_id();
-    GAS uint32_t *const row0 = rdfirst_gptr(sc.rows);  // lane 0's row (row_base(0) = 0)
-    GAS uint32_t *const pathg = rdfirst_gptr(sc.path);
+    GAS uint32_t *const row0 = rdfirst_gptr(rows_);  // lane 0's row (row_base(0) = 0)
     uint32_t n = 0, why = R_LIMIT;
-    while (n < 256u) {
+    while (n < 192u) {
         if (pos >= end_bit) {
             why = R_NEED_INPUT;
             break;
@@ -1458,10 +1166,12 @@ __device__ CHIP_PHASE_FN uint32_t serial_round(WaveLds &L, InWin &w, uint32_t po
         n++;
         pos += tb;
     }
+    WSYNC();  // the tokens have landed; the header window is done with
     if (lane == 0) {
-        pathg[0] = 0;
-        pathg[1] = 0;
+        L.fl.pk[0] = 0;
+        L.fl.pk[1] = 0;
     }
+    WSYNC();
     ntok_out = n;
     term_why = why;
     term_pos = pos;
@@ -1471,12 +1181,11 @@ __device__ CHIP_PHASE_FN uint32_t serial_round(WaveLds &L, InWin &w, uint32_t po
 // Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them into gout.  On return `pos` is
 // behind the end-of-block code (status stays ST_RUNNING) or status holds the reason decoding stopped.
 __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                                           const uint32_t cap, int32_t &status, const Scratch &sc, const uint32_t eob_len, const bool serial STAT_PARAM)
+                                           const uint32_t cap, int32_t &status, uint32_t *rows, const uint32_t xt_bits, const uint32_t eob_len,
+                                           const bool serial STAT_PARAM)
 {
-    const uint32_t lane = lane_id();
     pos = rdfirst(pos);
     opos = rdfirst(opos);
-    GAS const uint32_t *const pathg = rdfirst_gptr(sc.path);
     for (;;) {
         if (pos >= end_bit) {
             status = CHIP_NEED_INPUT;
@@ -1484,43 +1193,13 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         }
         STAT_T0();
         uint32_t ntok = 0, why = 0, tpos = 0, npk;
-        if (serial) {
-            npk = serial_round(L, w, pos, end_bit, sc, ntok, why, tpos);
-        } else {
-            const uint32_t P = walk_round(L, w, pos, end_bit, sc STAT_ARG);
-            STAT_ACC(2);
-            npk = resolve_path(L, sc, P, pos, ntok, why, tpos STAT_ARG);
-        }
-        STAT_ACC(3);
-        // the true stream, executed 64 pieces at a time; a batch's descriptions are fetched while the batch before it is executed
+        if (serial) npk = serial_round(L, w, pos, end_bit, rows, ntok, why, tpos);
+        else npk = walk_round(L, w, pos, end_bit, rows, xt_bits, ntok, why, tpos STAT_ARG);
         int32_t st2 = ST_RUNNING;
         bool flushed = true;
-        WSYNC();  // the descriptions have landed
-        uint32_t f = 0, d = 0, fend = ntok;
-        if (lane < npk) {
-            f = pathg[2u * lane];
-            d = pathg[2u * lane + 1u];
-        }
-        if (64u < npk) fend = pathg[2u * 64u];  // same word in every lane
-        for (uint32_t b = 0; b < npk; b += 64) {
-            const uint32_t nb = npk - b < 64u ? npk - b : 64u;
-            WSYNC();  // the flush before is done with the LDS
-            const uint32_t base = rdlane(f, 0);
-            L.fl.pk[2u * lane] = f - base;
-            L.fl.pk[2u * lane + 1u] = ((d + base) & 0xffffu) | (d & 0xffff0000u);
-            const uint32_t T = rdfirst(fend) - base;
-            if (b + 64u + lane < npk) {
-                f = pathg[2u * (b + 64u + lane)];
-                d = pathg[2u * (b + 64u + lane) + 1u];
-            }
-            fend = b + 128u < npk ? pathg[2u * (b + 128u)] : ntok;
-            WSYNC();
-            STAT_ACC(7);
-            flushed = flush_tokens(L, sc.rows, T, nb, gout, opos, cap, st2 STAT_ARG);
-            STAT_ACC(20);
-            if (!flushed) break;
-        }
+        if (npk) flushed = flush_tokens(L, rows, ntok, npk, gout, opos, cap, st2 STAT_ARG);
         w.win0 = 0xffffffffu;  // the phases used the header window's place
+        STAT_ACC(20);
         if (!flushed) {
             status = st2;
             return;
@@ -1533,27 +1212,20 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
             pos = tpos + eob_len;
             return;
         }
-        STAT_ADD(23, 1);
-        if (why != R_LIMIT || tpos <= pos) {  // invalid code (a round always gets past its first token otherwise)
+        if (why != R_LIMIT || tpos <= pos) {  // invalid code (a super-round always gets past its first token otherwise)
             status = Z_DATA_ERROR;
             return;
         }
-        pos = tpos;  // the round ended before the block did: on from where the true stream stopped
+        pos = tpos;  // on from where the true stream stopped
     }
 }
 
 #ifndef CHIP_WAVES_PER_SIMD
 #define CHIP_WAVES_PER_SIMD 4
 #endif
-// one unit, start to finish, by the calling wave; scratch = the wave's token rows, piece records, path list and marks in HBM
+// one unit, start to finish, by the calling wave; scratch = the wave's token rows in HBM
 __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, uint32_t *scratch)
 {
-    Scratch sc;
-    sc.rows = scratch;
-    sc.rec = (uint2 *)(scratch + ROWS_WORDS);
-    sc.path = scratch + ROWS_WORDS + 2 * PMAX;
-    sc.marks = scratch + ROWS_WORDS + 4 * PMAX;
-    sc.dump = scratch + ROWS_WORDS + 4 * PMAX + 8 * PMAX + 64;
     const uint32_t lane = lane_id();
 
     const uint8_t *gin = a.in_base + a.in_off[u];
@@ -1774,7 +1446,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
         }
         STAT_ACC(0);
         __builtin_amdgcn_s_setprio(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status, sc, eob_len, serial STAT_ARG);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len, serial STAT_ARG);
         __builtin_amdgcn_s_setprio(2);  // block headers and table builds are short dependent chains: ahead of the other waves' bulk work
         STAT_T0();
     }
