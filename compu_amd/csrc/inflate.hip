@@ -179,8 +179,8 @@ constexpr uint32_t TOK_RING = 4;   // token groups on their way from the scratch
 static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 == 0 && IMG_WORDS % 2 == 0, "geometry");
 
 constexpr uint32_t FLUSH_BYTES = 4 * (IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING + 128);
-constexpr uint32_t SERIAL_BYTES = 2 * 288 + 2 * 32 + 2 * sizeof(HuffMeta);  // what the serial fallback keeps behind the flush's state
-constexpr uint32_t PHASE_BYTES = 8 * WIN_DW > FLUSH_BYTES + SERIAL_BYTES ? 8 * WIN_DW : FLUSH_BYTES + SERIAL_BYTES;
+constexpr uint32_t HDR_BYTES = 4 * HDR_IN_DW + 4 * (1 << CL_ROOT) + 80 + sizeof(HuffMeta) + 64 + 320 + 2 * 288 + 2 * 32 + 2 * sizeof(HuffMeta);
+constexpr uint32_t PHASE_BYTES = 8 * WIN_DW > FLUSH_BYTES ? (8 * WIN_DW > HDR_BYTES ? 8 * WIN_DW : HDR_BYTES) : (FLUSH_BYTES > HDR_BYTES ? FLUSH_BYTES : HDR_BYTES);
 constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - PHASE_BYTES) / 4;
 constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;
 
@@ -190,15 +190,14 @@ struct alignas(16) WaveLds {
             uint32_t win[WIN_DW];            // input dwords from the super-round's first on
             uint32_t bm[WIN_DW];             // mark bits, one per input bit
         } w;
-        struct {                             // block header and table build; sorted[] and the descriptions stay for the (slow) fallback
+        struct {                             // block header and table build
             uint32_t inbuf[HDR_IN_DW];
             uint32_t cl_lut[1 << CL_ROOT];
             uint32_t cl_sorted[20];
             HuffMeta cl_h;
             uint32_t count[16];
             uint8_t lens[320];
-            uint8_t pad_[PHASE_BYTES - 4 * HDR_IN_DW - 4 * (1 << CL_ROOT) - 80 - sizeof(HuffMeta) - 64 - 320 - 2 * 288 - 2 * 32 - 2 * sizeof(HuffMeta)];
-            uint16_t lit_sorted[288];        // symbols in canonical order (behind everything the flush overlays)
+            uint16_t lit_sorted[288];        // symbols in canonical order
             uint16_t dist_sorted[32];
             HuffMeta lit_h, dist_h;
         } hdr;
@@ -215,7 +214,11 @@ struct alignas(16) WaveLds {
     uint32_t pool[POOL_WORDS];  // literal/length finals and sub-tables from the bottom, distance sub-tables (16-bit) from the top
 };
 static_assert(sizeof(WaveLds) <= 10240, "16 waves per CU: LDS is granted in 1280-byte steps");
-static_assert(offsetof(WaveLds, hdr.lit_sorted) >= offsetof(WaveLds, fl.pk) + 512, "the fallback's tables survive the flush");
+// pool[] cannot overflow.  In a canonical code the codes of one length are neighbours, so every 9-bit prefix that lies inside the codes
+// of length L > 9 has a sub-table of 2^(L-9) entries, one per code; only the (at most one per length) prefixes that straddle two lengths
+// hold entries that repeat a code.  Literal/length: <= 286 codes + 1 invalid entry + (2 + 4 + ... + 64) = 413 words; distance (16-bit
+// entries, 8-bit root): <= 30 + (2 + 4 + ... + 128) = 284 entries = 142 words.
+static_assert(POOL_WORDS >= 413 + 142, "the tables of any valid block fit");
 // the CRC-32 tables (2048 words) take the whole structure: nothing else is live while a checksum runs
 static_assert(sizeof(WaveLds) >= 2048 * 4, "wave_crc32 needs 8 KB");
 
@@ -303,8 +306,8 @@ __device__ CHIP_PHASE_FN int build_cl_table(WaveLds &L)
     return 0;
 }
 
-// Literal/length tables of a block from lens[0..n).  Returns 0, -1 (invalid set), or 1: the codes' entries do not fit pool[]
-// (the caller then decodes the block with the serial fallback).  `used` = words of pool[] taken.
+// Literal/length tables of a block from lens[0..n).  Returns 0, -1 (invalid set), or 1 (the codes' entries do not fit pool[]: cannot
+// happen, see POOL_WORDS).  `used` = words of pool[] taken.
 __device__ CHIP_PHASE_FN int build_litlen(WaveLds &L, const uint8_t *lens, int n, uint32_t &used)
 {
     const uint32_t lane = lane_id();
@@ -820,42 +823,62 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         static_assert(TOK_RING == 4, "the wait below counts three younger ring loads");
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the load into slot_r has landed
         const uint32_t t = C.tok[64u * slot_r + lane];
-        const uint32_t nvalid = ntok - c0 < 64u ? ntok - c0 : 64u;
         // token: [8:0] literal byte or match length, [9] match, [25:10] distance - 1
         const uint32_t ism = (uint32_t)__builtin_amdgcn_sbfe((int)t, 9, 1);  // all ones for a match
         const uint32_t tv = t & 0x1ffu;
         const uint32_t len = tv & ism;
         const uint32_t dist = __builtin_amdgcn_ubfe(t, 10, 16) + 1u;
         const uint32_t val = (dist & ism) | (tv & ~ism);
-        const uint32_t olen = lane < nvalid ? (len > 1u ? len : 1u) : 0u;
+        const uint32_t left = ntok - c0;
+        uint32_t olen = len > 1u ? len : 1u;
+        if (left < 64u) olen = lane < left ? olen : 0u;  // (uniform: the last group of a batch)
         const uint32_t incl = wave_incl_scan(olen);
         const uint32_t start = run + incl - olen;
-        // stops: the first token that does not fit the chunk, or with an "invalid distance too far back" (the distance
-        // reaches before the first output byte)
+        const uint32_t total = rdlane(incl, 63u);
         const uint64_t lenm = __ballot(len != 0);
-        const uint64_t validm = nvalid == 64u ? ~0ull : (1ull << nvalid) - 1ull;
-        const uint64_t nofit = __ballot(incl > CHUNK_BYTES - run) & validm;
-        const uint64_t badm = __ballot(val > prod0 + start) & lenm & validm;
-        const uint64_t stopm = nofit | badm;
-        uint32_t nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : nvalid;
-        // a group that does not fit is left whole to the next chunk (the prefetched group stays the right one) unless the
-        // chunk is empty (long matches: 64 tokens can be 16 KB) or the stop is an error
-        const bool too_far = stopm != 0 && ((badm & ~nofit) >> nacc) & 1ull;
-        if (stopm && !too_far && run != mis) nacc = 0;
-        if (lane < nacc && len == 0) img[start] = (uint8_t)val;
-        const uint64_t mm = lenm & (nacc == 64u ? ~0ull : (1ull << nacc) - 1ull);
-        if (lane < nacc && len != 0) {
-            const uint32_t qi = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, nq)) & (MQ_CAP - 1u);
-            C.mq[qi] = make_uint2(start, len | (val << 16));
-        }
-        nq += (uint32_t)__popcll(mm);
-        c0 += nacc;
-        if (stopm) {
-            if (nacc) run = rdlane(start, nacc);
+        uint32_t nacc;
+        bool ending, too_far = false;
+        // The common group: 64 tokens that all fit the chunk, no distance reaching in front of the output's first byte.
+        if (left >= 64u && run + total <= CHUNK_BYTES && !__any(len != 0 && val > prod0 + start)) {
+            asm volatile("; the common group" ::: "memory");  // (keeps the compiler from folding this path into the general one below)
+            if (len == 0) img[start] = (uint8_t)val;
+            else {
+                const uint32_t qi = __builtin_amdgcn_mbcnt_hi((uint32_t)(lenm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lenm, nq)) & (MQ_CAP - 1u);
+                C.mq[qi] = make_uint2(start, len | (val << 16));
+            }
+            nq += (uint32_t)__popcll(lenm);
+            c0 += 64u;
+            run += total;
+            nacc = 64u;
+            ending = c0 >= ntok;
         } else {
-            run += rdlane(incl, 63u);
+            const uint32_t nvalid = left < 64u ? left : 64u;
+            // stops: the first token that does not fit the chunk, or with an "invalid distance too far back" (the distance
+            // reaches before the first output byte)
+            const uint64_t validm = nvalid == 64u ? ~0ull : (1ull << nvalid) - 1ull;
+            const uint64_t nofit = __ballot(incl > CHUNK_BYTES - run) & validm;
+            const uint64_t badm = __ballot(val > prod0 + start) & lenm & validm;
+            const uint64_t stopm = nofit | badm;
+            nacc = stopm ? (uint32_t)__ffsll((long long)stopm) - 1u : nvalid;
+            // a group that does not fit is left whole to the next chunk (the prefetched group stays the right one) unless the
+            // chunk is empty (long matches: 64 tokens can be 16 KB) or the stop is an error
+            too_far = stopm != 0 && ((badm & ~nofit) >> nacc) & 1ull;
+            if (stopm && !too_far && run != mis) nacc = 0;
+            if (lane < nacc && len == 0) img[start] = (uint8_t)val;
+            const uint64_t mm = lenm & (nacc == 64u ? ~0ull : (1ull << nacc) - 1ull);
+            if (lane < nacc && len != 0) {
+                const uint32_t qi = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, nq)) & (MQ_CAP - 1u);
+                C.mq[qi] = make_uint2(start, len | (val << 16));
+            }
+            nq += (uint32_t)__popcll(mm);
+            c0 += nacc;
+            if (stopm) {
+                if (nacc) run = rdlane(start, nacc);
+            } else {
+                run += total;
+            }
+            ending = stopm != 0 || c0 >= ntok;  // the chunk ends with this group
         }
-        const bool ending = stopm != 0 || c0 >= ntok;  // the chunk ends with this group
         LSYNC();  // literals and queue entries are in LDS; the slot's tokens are in registers
         STAT_ACC(16);
         // ---- match rounds.  A round's source loads are started as soon as 64 matches are queued and it is finished
@@ -1091,15 +1114,6 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         L.fl.pk[2u * k] = first;
         L.fl.pk[2u * k + 1u] = ((e_a0 - first) & 0xffffu) | (row_base(node) << 16);  // row token = stream index + (a0 - first)
     }
-#ifdef CHIP_STATS
-    if (st_[8] == 1) {  // debug: the unit's first super-round
-        st_[22] = ((unsigned long long)rdlane(nst, 0) << 48) | ((unsigned long long)rdlane(why, 0) << 40) | ((unsigned long long)(rdlane(p, 0) - B) << 16) | (rdlane(jl, 0) << 8) | rdlane(a_join, 0);
-        st_[23] = ((unsigned long long)rdlane(nst, 1) << 48) | ((unsigned long long)rdlane(why, 1) << 40) | ((unsigned long long)(rdlane(p, 1) - B) << 16) | (rdlane(jl, 1) << 8) | rdlane(a_join, 1);
-        st_[19] = ((unsigned long long)rdlane(node, 1) << 48) | ((unsigned long long)rdlane(node, 2) << 40) | ((unsigned long long)rdlane(cnt, 0) << 24) | ((unsigned long long)rdlane(cnt, 1) << 8) | (B & 31u);
-        st_[6] = ((unsigned long long)rdlane(e_a0, 1) << 32) | rdlane(e_nst, 1);
-        st_[0] = ((unsigned long long)L.w.bm[((B + S_BITS) >> 5) - D0] << 32) | L.w.bm[((B + S_BITS) >> 5) - D0 + 1];
-    }
-#endif
     const uint32_t kz = rdlane(node, 63);  // the chain the stream ends in
     term_why = rdlane(why, kz);
     term_pos = rdlane(p, kz);
@@ -1112,77 +1126,10 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
 }
 
 // ---- a block's tokens: super-rounds of walk, path resolve, execution ------------------------------------
-// Serial stand-in for a super-round's walk, for a block whose tables do not fit pool[] (more than ~600 table entries behind the
-// 9-bit root: possible in theory, not seen): up to 192 tokens, one at a time, every lane doing the same work, codes resolved
-// canonically from the sorted symbols that the table build leaves at the end of the header's LDS.  The tokens go to lane 0's
-// row as one piece.  Slow; exists so that every valid stream decodes.
-__device__ CHIP_PHASE_FN uint32_t serial_round(WaveLds &L, InWin &w, uint32_t pos, const uint32_t end_bit, uint32_t *rows_, uint32_t &ntok_out,
-                                               uint32_t &term_why, uint32_t &term_pos)
-{
-    const uint32_t lane = lane_id();
-    GAS uint32_t *const row0 = rdfirst_gptr(rows_);  // lane 0's row (row_base(0) = 0)
-    uint32_t n = 0, why = R_LIMIT;
-    while (n < 192u) {
-        if (pos >= end_bit) {
-            why = R_NEED_INPUT;
-            break;
-        }
-        win_ensure(L, w, pos, 64);
-        uint32_t lo, hi;
-        win_bits_uniform(L, w, pos, lo, hi);
-        uint32_t l;
-        const uint32_t ci = canon_index(L.hdr.lit_h, __brev(lo) >> 17, l);
-        const uint32_t e = ci == 0xffffffffu ? (rdfirst(L.hdr.lit_h.maxlen) | F_HALT | F_INV) : make_final(L.hdr.lit_sorted[ci], l);
-        const uint32_t cl = e & 31u, eb = (e >> 5) & 31u, n1 = cl + eb;
-        uint32_t tb = n1;
-        uint32_t tok = bfe(lo, cl, eb) + bfe(e, 16, 9);
-        bool bad = (e & F_HALT) && (e & F_INV);
-        const bool eob = (e & F_HALT) && !(e & F_INV);
-        if (e & F_LEN) {
-            const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
-            uint32_t l2;
-            const uint32_t di = canon_index(L.hdr.dist_h, __brev(w2) >> 17, l2);
-            const uint32_t dmax = rdfirst(L.hdr.dist_h.maxlen);
-            const uint32_t m = di == 0xffffffffu ? ((dmax ? dmax : 1u) | D_BAD) : make_dist16(L.hdr.dist_sorted[di], l2);
-            const uint32_t cl2 = m & 15u, eb2 = bfe(m, 4, 4);
-            tb += cl2 + eb2;
-            tok |= 512u | (((bfe(m, 8, 2) << eb2) + bfe(w2, cl2, eb2)) << 10);
-            bad = bad || (m & D_BAD);
-        }
-        tb = rdfirst(tb);
-        if (pos + tb > end_bit) {  // zlib's order of verdicts: input exhausted inside the token, then end of block, then invalid codes
-            why = R_NEED_INPUT;
-            break;
-        }
-        if (rdfirst((uint32_t)eob)) {
-            why = R_EOB;
-            break;
-        }
-        if (rdfirst((uint32_t)bad)) {
-            why = R_BAD;
-            break;
-        }
-        if (lane == 0) row0[row_word(n)] = tok;
-        n++;
-        pos += tb;
-    }
-    WSYNC();  // the tokens have landed; the header window is done with
-    if (lane == 0) {
-        L.fl.pk[0] = 0;
-        L.fl.pk[1] = 0;
-    }
-    WSYNC();
-    ntok_out = n;
-    term_why = why;
-    term_pos = pos;
-    return n ? 1u : 0u;
-}
-
 // Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them into gout.  On return `pos` is
 // behind the end-of-block code (status stays ST_RUNNING) or status holds the reason decoding stopped.
 __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                                           const uint32_t cap, int32_t &status, uint32_t *rows, const uint32_t xt_bits, const uint32_t eob_len,
-                                           const bool serial STAT_PARAM)
+                                           const uint32_t cap, int32_t &status, uint32_t *rows, const uint32_t xt_bits, const uint32_t eob_len STAT_PARAM)
 {
     pos = rdfirst(pos);
     opos = rdfirst(opos);
@@ -1192,9 +1139,8 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
             return;
         }
         STAT_T0();
-        uint32_t ntok = 0, why = 0, tpos = 0, npk;
-        if (serial) npk = serial_round(L, w, pos, end_bit, rows, ntok, why, tpos);
-        else npk = walk_round(L, w, pos, end_bit, rows, xt_bits, ntok, why, tpos STAT_ARG);
+        uint32_t ntok = 0, why = 0, tpos = 0;
+        const uint32_t npk = walk_round(L, w, pos, end_bit, rows, xt_bits, ntok, why, tpos STAT_ARG);
         int32_t st2 = ST_RUNNING;
         bool flushed = true;
         if (npk) flushed = flush_tokens(L, rows, ntok, npk, gout, opos, cap, st2 STAT_ARG);
@@ -1247,7 +1193,6 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
     bool last = false;
     int tables = 0;  // 0 none, 1 fixed, 2 dynamic
     uint32_t eob_len = 0;   // length of the block's end-of-block code
-    bool serial = false;    // the block's tables do not fit the LDS pool: decode it with the serial fallback
 
     STAT_DECL;
     STAT_T0();
@@ -1436,17 +1381,16 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
             eob_len = rdfirst(L.hdr.lens[256]);
             uint32_t used = 0;
             const int r1 = build_litlen(L, L.hdr.lens, (int)nlen, used);
-            const int r2 = r1 < 0 ? r1 : build_dist(L, L.hdr.lens + nlen, (int)ndist, r1 ? POOL_WORDS : used);
-            if (r1 < 0 || r2 < 0) {
+            const int r2 = r1 ? r1 : build_dist(L, L.hdr.lens + nlen, (int)ndist, used);
+            if (r1 || r2) {  // an invalid set of code lengths (the pool cannot overflow: see POOL_WORDS)
                 status = Z_DATA_ERROR;
                 break;
             }
-            serial = r1 > 0 || r2 > 0;
             STAT_ACC(5);
         }
         STAT_ACC(0);
         __builtin_amdgcn_s_setprio(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len, serial STAT_ARG);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len STAT_ARG);
         __builtin_amdgcn_s_setprio(2);  // block headers and table builds are short dependent chains: ahead of the other waves' bulk work
         STAT_T0();
     }

@@ -33,8 +33,8 @@ b.record()
 torch.cuda.synchronize()
 assert (st == 2).all() and torch.equal(d_out, torch.from_numpy(pay).to(dev))
 s = stats.cpu().numpy().reshape(n, 24).astype(np.float64)
-names = ["hdr other", "walk setup", "walk", "resolve", "hdr:codelens", "hdr:build", "trailer", "flush prep", "walk rounds", "path pieces", "tokens", "walk trips", "copy passes",
-         "chunks", "match rounds", "wave copies", "fl:token groups", "fl:match rounds", "fl:chunk store", "pieces claimed", "fl:tail", "lane-groups", "rounds ended by the EOB guess", "rounds ended in LIMIT"]
+names = ["hdr other", "window load", "walk", "resolve", "hdr:codelens", "hdr:build", "trailer", "-", "super-rounds", "path pieces", "tokens", "walk trips", "copy passes",
+         "chunks", "match rounds", "wave copies", "fl:token groups", "fl:match rounds", "fl:chunk store", "-", "fl:tail", "lanes walking", "-", "-"]
 tot = s[:, :8].sum(axis=1).mean() + s[:, 16:21].sum(axis=1).mean()
 print(f"kind={kind} units={n} kernel={a.elapsed_time(b):.3f} ms; mean cycles/unit {tot:.0f}")
 for i, nm in enumerate(names):
@@ -42,4 +42,4 @@ for i, nm in enumerate(names):
         continue
     m = s[:, i].mean()
     print(f"  {nm:14s} {m:12.1f}" + (f"  ({100 * m / tot:5.1f}%)" if (i < 8 or i >= 16) else ""))
-print(f"  walk rounds/unit {s[:, 8].mean():.2f}; trips/unit {s[:, 11].mean():.0f} (x8 tokens); pieces claimed {s[:, 19].mean():.0f}, on path {s[:, 9].mean():.0f}; tokens/unit {s[:, 10].mean():.0f}; lane-groups (4 tokens) {s[:, 21].mean():.0f}; passes per round {s[:, 12].sum() / max(1, s[:, 14].sum()):.2f}")
+print(f"  super-rounds/unit {s[:, 8].mean():.2f}; walk trips/unit {s[:, 11].mean():.0f} (x4 tokens); lanes on the path per super-round {s[:, 9].sum() / s[:, 8].sum():.1f}; tokens/unit {s[:, 10].mean():.0f}; passes per match round {s[:, 12].sum() / max(1, s[:, 14].sum()):.2f}")
