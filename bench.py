@@ -87,12 +87,16 @@ def run_encode(torch, compu_amd, payload_dev, n_units, steps, warmup, dist, leve
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    d_out.fill_(0xA5)  # the verification below speaks for the timed launches (see run_workload)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in evs:
+    for i, (a, b) in enumerate(evs):
+        if i == steps - 1:
+            d_out_len.fill_(-1)
+            d_status.fill_(-99)
         a.record()
         step()
         b.record()
@@ -138,12 +142,21 @@ def run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps,
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
+    # The verification below must speak for the TIMED launches, not for the warm-up: the output is poisoned before the timed region
+    # (some timed launch has to write all of it) and the result words before the last timed launch (that launch has to succeed; three
+    # small fills, 0.8 MB, between two steps).
+    if verify:
+        d_out.fill_(0xA5)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in evs:
+    for i, (a, b) in enumerate(evs):
+        if verify and i == steps - 1:
+            d_out_len.fill_(-1)
+            d_in_used.fill_(-1)
+            d_status.fill_(-99)
         a.record()  # same (current) stream the launch goes to
         step()
         b.record()
@@ -171,16 +184,85 @@ def run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps,
     }
 
 
-def cpu_baseline(packed, offs, lens, n_sample, threads):
-    """The oracle (CPU restatement of compu's zlib decode loop) on a bounded sample; rank 0, N=1 only."""
+def _try_zlib_ng(parts, threads):
+    """compu's actual CPU backend is zlib-ng (libz-ng-sys); it is not vendored in /root/reference and cannot be built here, so it is
+    bound at run time when the host has it.  Returns a result dict or a note saying why not."""
+    import ctypes as C
+
+    try:
+        z = C.CDLL("libz-ng.so.2")
+    except OSError as e:
+        return {"available": False, "note": f"libz-ng.so.2 not present on this host ({e}); the oracle port is the baseline"}
+
+    class ZngStream(C.Structure):  # zng_stream of zlib-ng 2.x (native API)
+        _fields_ = [("next_in", C.c_void_p), ("avail_in", C.c_uint32), ("total_in", C.c_size_t), ("next_out", C.c_void_p), ("avail_out", C.c_uint32),
+                    ("total_out", C.c_size_t), ("msg", C.c_char_p), ("state", C.c_void_p), ("zalloc", C.c_void_p), ("zfree", C.c_void_p),
+                    ("opaque", C.c_void_p), ("data_type", C.c_int), ("adler", C.c_uint32), ("reserved", C.c_ulong)]
+
+    try:
+        z.zng_inflateInit2.argtypes = [C.POINTER(ZngStream), C.c_int]
+        z.zng_inflate.argtypes = [C.POINTER(ZngStream), C.c_int]
+        z.zng_inflateReset.argtypes = [C.POINTER(ZngStream)]
+        z.zng_inflateEnd.argtypes = [C.POINTER(ZngStream)]
+        ver = C.c_char_p.in_dll(z, "zlibng_version") if hasattr(z, "zlibng_version") else None
+    except AttributeError as e:
+        return {"available": False, "note": f"libz-ng.so.2 lacks the native zng_ API ({e})"}
+    from concurrent.futures import ThreadPoolExecutor
+
+    m = len(parts)
+    outs = [np.empty(UNIT, np.uint8) for _ in range(threads)]
+
+    def work(k):  # compu's loop (src/decoder/zlib_ng.rs:61-108): one stream per worker, reset per unit
+        st = ZngStream()
+        if z.zng_inflateInit2(C.byref(st), -15) != 0:
+            return -1
+        tot = 0
+        for i in range(k, m, threads):
+            src = parts[i]
+            st.next_in = C.cast(C.c_char_p(src), C.c_void_p)
+            st.avail_in = len(src)
+            st.next_out = outs[k].ctypes.data
+            st.avail_out = UNIT
+            if z.zng_inflate(C.byref(st), 0) != 1:  # Z_STREAM_END
+                return -1
+            tot += UNIT - st.avail_out
+            z.zng_inflateReset(C.byref(st))
+        z.zng_inflateEnd(C.byref(st))
+        return tot
+
+    with ThreadPoolExecutor(threads) as ex:
+        t0 = time.perf_counter()
+        tot = list(ex.map(work, range(threads)))
+        dt = time.perf_counter() - t0
+    if min(tot) < 0 or sum(tot) != m * UNIT:
+        return {"available": True, "note": "zng_inflate did not decode the sample"}
+    return {"available": True, "value": round(sum(tot) / dt / 1e9, 3), "unit": "GB/s", "threads": threads, "version": ver.value.decode() if ver else "?",
+            "sample": f"first {m} units, zng_inflate through ctypes (the library releases no GIL by itself: ctypes does around each call)"}
+
+
+def cpu_baseline(packed, offs, lens, n_sample, threads, kind="dynamic", unit_kinds=None):
+    """The oracle (CPU restatement of compu's decode loops) on a bounded sample; rank 0, N=1 only.  `mixed`: gzip units through the
+    inflate oracle, zstd frames through the zstd oracle (unit_kinds[i] = 1 for gzip), timed together."""
     from oracle import oracle as O
 
     n = min(n_sample, len(lens))
+    O.lib()
+    out = np.ones(n * UNIT, np.uint8)  # allocated and touched before the clock starts
     out_off = np.arange(n, dtype=np.uint64) * UNIT
     out_cap = np.full(n, UNIT, np.uint32)
-    O.lib()
     best = None
-    out = np.ones(n * UNIT, np.uint8)  # allocated and touched before the clock starts
+    if kind == "mixed":
+        gz = np.nonzero(unit_kinds[:n] == 1)[0]
+        zs = np.nonzero(unit_kinds[:n] != 1)[0]
+        for _ in range(3):
+            t0 = time.perf_counter()
+            _o, l1, s1, b1 = O.inflate_units(O.MODE_GZIP, packed, offs[gz], lens[gz], n * UNIT, out_off[gz], out_cap[gz], threads=threads, out=out)
+            _o, l2, s2, b2 = O.zstd_units(packed, offs[zs], lens[zs], n * UNIT, out_off[zs], out_cap[zs], threads=threads, out=out)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        assert b1 == 0 and b2 == 0 and (l1 == UNIT).all() and (l2 == UNIT).all()
+        return {"value": round(n * UNIT / best / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+                "sample": f"first {n} units of the same batch ({len(gz)} gzip through oracle/oracle_inflate.c, {len(zs)} zstd through oracle/oracle_zstd.c), best of 3"}
     for _ in range(3):
         t0 = time.perf_counter()
         _out, out_len, status, bad = O.inflate_units(O.MODE_DEFLATE, packed, offs[:n], lens[:n], n * UNIT, out_off, out_cap, threads=threads, out=out)
@@ -194,13 +276,17 @@ def cpu_baseline(packed, offs, lens, n_sample, threads):
         "kind": "port",
         "sample": f"first {n} units of the same batch ({n * UNIT / 2**20:.0f} MiB out), oracle/oracle_inflate.c, one decoder per thread reset per unit, output pre-touched, best of 3",
     }
+    m = min(n, 16384)
+    parts = [bytes(packed[int(offs[i]) : int(offs[i]) + int(lens[i])]) for i in range(m)]
+    # compu's real CPU backend, when the host has it (never the case in this image: stated either way)
+    try:
+        res["zlib_ng"] = _try_zlib_ng(parts, threads)
+    except Exception as e:
+        res["zlib_ng"] = {"available": False, "note": f"probe failed: {e}"}
     # for orientation only (not the baseline): the host's system zlib on a slice of the same sample, same thread count
     try:
         import zlib
         from concurrent.futures import ThreadPoolExecutor
-
-        m = min(n, 16384)
-        parts = [bytes(packed[int(offs[i]) : int(offs[i]) + int(lens[i])]) for i in range(m)]
 
         def work(rng):
             tot = 0
@@ -283,8 +369,9 @@ def main():
     if "BENCH_DEVICE_OVERRIDE" not in os.environ and local_rank >= visible:
         log(f"[bench] error: rank {rank} needs GPU {local_rank} but only {visible} device(s) are visible")
         sys.exit(2)
-    # rehearsal knobs (not used by the driver): several ranks on one GPU need gloo, NCCL/RCCL refuses duplicate devices
-    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    # The ranks share nothing but a barrier and the max-over-ranks clock (north_star: "no RCCL needed"): gloo carries both, and a rank's
+    # failure to bring up RCCL cannot sink the scaling run.  BENCH_DEVICE_OVERRIDE is a rehearsal knob (several ranks on one GPU).
+    backend = os.environ.get("BENCH_DIST_BACKEND", "gloo")
     if "BENCH_DEVICE_OVERRIDE" in os.environ:
         local_rank = int(os.environ["BENCH_DEVICE_OVERRIDE"])
     torch.cuda.set_device(local_rank)
@@ -310,10 +397,11 @@ def main():
     d_expect = torch.from_numpy(payload).to(torch.device("cuda", local_rank))
 
     kinds = [args.workload]
-    if args.extra and world == 1:
-        kinds += [k for k in ("stored", "fixed") if k != args.workload]
+    if args.extra and world == 1:  # every BASELINE config in the one run the driver makes: cfg1 (stored, fixed), cfg4 (mixed), cfg3 (encode)
+        kinds += [k for k in ("stored", "fixed", "mixed", "encode") if k != args.workload]
     results = {}
     cpu = None
+    cpu_extra = {}
     for kind in kinds:
         steps = args.steps if kind == args.workload else max(3, min(args.steps, 5))
         if kind == "encode":
@@ -327,16 +415,30 @@ def main():
         res["steps"] = steps
         results[kind] = res
         log(f"[bench] {kind}: kernel {res['kernel_ms_avg']:.3f} ms avg, verified={res['verified']}")
-        if kind == args.workload and kind != "mixed" and rank == 0 and world == 1 and not args.no_cpu:
-            cpu = cpu_baseline(packed, offs, lens, args.cpu_sample, threads=ncpu)
+        if rank == 0 and world == 1 and not args.no_cpu and kind in (args.workload, "mixed"):
+            uk = None
+            if kind == "mixed":
+                uk = np.array([synth._splitmix64(first_unit + i) & 1 for i in range(n_units)], dtype=np.uint8)
+            # the headline workload gets the full sample, a side workload a quarter of it (the default run stays within minutes)
+            c = cpu_baseline(packed, offs, lens, args.cpu_sample if kind == args.workload else args.cpu_sample // 4, threads=ncpu, kind=kind, unit_kinds=uk)
+            if kind == args.workload:
+                cpu = c
+            else:
+                cpu_extra[kind] = c
         del packed
 
+    main_res = results[args.workload]
+    rank_ms = [main_res["kernel_ms_avg"]]
+    if dist is not None:  # every rank's mean kernel time (the ranks run the same number of units: the spread is the devices')
+        t = torch.zeros(world, dtype=torch.float64, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
+        t[rank] = main_res["kernel_ms_avg"]
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_ms = [float(x) for x in t.cpu()]
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
 
-    main_res = results[args.workload]
     value = shard.aggregate_rate(main_res["out_bytes"], world, main_res["steps"], main_res["elapsed_s"]) / 1e9
     ach = (main_res["comp_bytes"] + main_res["out_bytes"]) / (main_res["kernel_ms_avg"] * 1e-3) / 1e9
     names = {
@@ -383,6 +485,9 @@ def main():
             "algorithmic_bytes_per_launch": main_res["comp_bytes"] + main_res["out_bytes"],
             "kernel_ms_avg": round(main_res["kernel_ms_avg"], 4),
             "kernel_ms_min": round(main_res["kernel_ms_min"], 4),
+            "kernel_ms_avg_per_rank": {"min": round(min(rank_ms), 4), "max": round(max(rank_ms), 4)},
+            # all ranks' algorithmic bytes over the slowest rank's kernel time, against N x the peak
+            "frac_of_n_gpus_peak": round((main_res["comp_bytes"] + main_res["out_bytes"]) * world / (max(rank_ms) * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 5),
         },
         "cpu_baseline": cpu,
         "workloads": {
@@ -392,11 +497,16 @@ def main():
                 "hbm_frac": round((r["comp_bytes"] + r["out_bytes"]) / (r["kernel_ms_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5),
                 "kernel_ms_avg": round(r["kernel_ms_avg"], 4),
                 "compressed_ratio": round(r["comp_bytes"] / r["out_bytes"], 4),
+                "kernel": {"mixed": "chip::route_kernel + chip::inflate_kernel + chip::zstd_kernel", "encode": "chip::deflate_kernel" if args.encode_level == 1 else "chip::deflate_dyn_kernel"}.get(k, "chip::inflate_kernel"),
+                "traffic": None,
+                "cpu_baseline": cpu_extra.get(k),
                 "verified": r["verified"],
             }
             for k, r in results.items()
         },
     }
+    if "encode" in line["workloads"]:  # the encoder reads the payload and writes the compressed units
+        line["workloads"]["encode"]["input_GBps"] = line["workloads"]["encode"].pop("decompressed_GBps")
     traffic_file = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(traffic_file):
         try:
@@ -404,6 +514,8 @@ def main():
                 tr = json.load(f)
             line["roofline"]["traffic"] = tr.get(args.workload, {}).get("hbm_bytes_per_launch")
             line["roofline"]["traffic_source"] = tr.get("source")
+            for k in line["workloads"]:
+                line["workloads"][k]["traffic"] = tr.get(k, {}).get("hbm_bytes_per_launch")
         except Exception:
             pass
     print(json.dumps(line), flush=True)

@@ -159,6 +159,58 @@ def test_raw_deflate_64k_synthetic_units(gpu):
         assert b"".join(outs) == pay.tobytes(), kind
 
 
+def _skewed_payload(n_lit_syms, n, seed):
+    """Bytes whose literal AND match-distance statistics follow the Fibonacci numbers (the counts that make a Huffman tree as deep
+    as it can get): zlib's codes then reach its 15-bit limit on both alphabets within one 16 K-token block."""
+    rnd = random.Random(seed)
+    syms = list(range(256))
+    rnd.shuffle(syms)
+    syms = syms[:n_lit_syms]
+    fib = [1, 1]
+    while len(fib) < 64:
+        fib.append(fib[-1] + fib[-2])
+    lw = [fib[min(k, 40)] for k in range(n_lit_syms)]
+    dcodes = list(range(30))
+    rnd.shuffle(dcodes)
+    dw = [fib[k] for k in range(30)]
+    out = bytearray(bytes(rnd.choices(syms, weights=lw, k=64)))
+    while len(out) < n:
+        if rnd.random() < 0.5:
+            out.append(rnd.choices(syms, weights=lw, k=1)[0])
+            continue
+        d_code = rnd.choices(dcodes, weights=dw, k=1)[0]
+        if d_code < 4:
+            dist = d_code + 1
+        else:
+            eb = (d_code >> 1) - 1
+            dist = 1 + ((2 + (d_code & 1)) << eb) + rnd.randrange(1 << eb)
+        if dist > len(out):
+            continue
+        for _ in range(rnd.choice([3, 3, 3, 4, 5, 9])):
+            out.append(out[-dist])
+    return bytes(out[:n])
+
+
+def test_deep_huffman_codes_use_the_subtables(gpu):
+    """Codes longer than the 9-bit (literal/length) and 8-bit (distance) roots: geometric symbol statistics drive zlib's trees to
+    15 bits, so most lookups of these streams go through the second-level tables; the oracle decides what is right."""
+    torch = gpu
+    parts, caps, want = [], [], []
+    for seed, (nsym, n) in enumerate([(40, 70000), (120, 200000), (256, 65536), (24, 300000), (200, 400000)]):
+        pay = _skewed_payload(nsym, n, 100 + seed)
+        for level, strategy in ((6, zlib.Z_DEFAULT_STRATEGY), (9, zlib.Z_FILTERED), (1, zlib.Z_DEFAULT_STRATEGY)):
+            co = zlib.compressobj(level, zlib.DEFLATED, -15, 9, strategy)
+            parts.append(co.compress(pay) + co.flush())
+            caps.append(len(pay))
+            want.append(pay)
+    outs, ol, iu, st = run_batch(torch, -15, parts, caps)
+    ref = oracle_batch(0, parts, caps)
+    for i in range(len(parts)):
+        assert st[i] == ref[i][2] == 2, (i, st[i], ref[i][2])
+        assert outs[i] == want[i] == ref[i][0], f"stream {i} differs"
+        assert iu[i] == len(parts[i]) == ref[i][1]
+
+
 def test_truncated_corrupt_and_small_caps_match_oracle(gpu, alice):
     rnd = random.Random(5)
     parts, caps = [], []
