@@ -69,6 +69,24 @@ impl DeviceBuffer {
     }
 
     #[inline(always)]
+    ///Size of the allocation in bytes
+    pub fn capacity(&self) -> usize {
+        self.capacity
+    }
+
+    #[inline(always)]
+    ///DEVICE pointer to the buffer's first byte (for the batched entry points, which take whole buffers plus offsets)
+    pub fn as_ptr(&self) -> *const u8 {
+        self.buffer.as_ptr()
+    }
+
+    #[inline(always)]
+    ///Mutable DEVICE pointer to the buffer's first byte
+    pub fn as_mut_ptr(&mut self) -> *mut u8 {
+        self.buffer.as_ptr()
+    }
+
+    #[inline(always)]
     ///Marks internal buffer as consumed fully
     pub fn consume(&mut self) {
         self.cursor = 0;

@@ -44,6 +44,11 @@ pub struct chip_encoder_opts {
 }
 
 pub const CHIP_FMT_ZSTD: c_int = 100;
+///route every unit of a batch by `Detection::detect` (src/decoder/mod.rs:28-114)
+pub const CHIP_FMT_DETECT: c_int = 0;
+
+///`chip_decode_batch` / `chip_encode_batch` return codes
+pub const CHIP_OK: c_int = 0;
 
 pub type chip_malloc_fn = unsafe extern "C" fn(opaque: *mut c_void, size: usize) -> *mut c_void;
 pub type chip_free_fn = unsafe extern "C" fn(opaque: *mut c_void, ptr: *mut c_void);
@@ -60,14 +65,42 @@ extern "C" {
     pub fn chip_memcpy_d2h(dst_host: *mut c_void, src_dev: *const c_void, size: usize, stream: *mut c_void) -> c_int;
     pub fn chip_stream_sync(stream: *mut c_void) -> c_int;
 
+    pub fn chip_set_device(device: c_int) -> c_int;
+    pub fn chip_version() -> *const c_char;
+    pub fn chip_trim() -> c_int;
+
     pub fn chip_decoder_new(format: c_int, opts: *const chip_decoder_opts) -> *mut chip_decoder;
     pub fn chip_decode(d: *mut chip_decoder, input: *const u8, input_len: usize, output: *mut u8, output_len: usize) -> chip_decode_result;
     pub fn chip_decoder_reset(d: *mut chip_decoder) -> *mut chip_decoder;
     pub fn chip_decoder_free(d: *mut chip_decoder);
+    pub fn chip_decoder_footprint(d: *const chip_decoder, pinned_bytes: *mut usize, device_bytes: *mut usize);
     pub fn chip_decoder_strerror(format: c_int, code: i32) -> *const c_char;
+
+    // ---- the batched hot path (additive API): n independent units per launch, one wavefront per unit
+    pub fn chip_decode_batch(format: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, out_base: *mut c_void,
+                             out_off: *const u64, out_cap: *const u32, out_len: *mut u32, in_used: *mut u32, status: *mut i32, stream: *mut c_void) -> c_int;
+    pub fn chip_decode_batch_host(format: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, out_base: *mut c_void,
+                                  out_off: *const u64, out_cap: *const u32, out_len: *mut u32, in_used: *mut u32, status: *mut i32, device: c_int,
+                                  slice_bytes: usize) -> c_int;
+    pub fn chip_decode_batch_multi(format: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, out_base: *mut c_void,
+                                   out_off: *const u64, out_cap: *const u32, out_len: *mut u32, in_used: *mut u32, status: *mut i32,
+                                   devices: *const c_int, n_devices: c_int, slice_bytes: usize) -> c_int;
+    pub fn chip_partition_units(n: usize, in_len: *const u32, out_cap: *const u32, parts: c_int, cuts: *mut usize) -> c_int;
+    pub fn chip_detect(bytes: *const u8, len: usize) -> c_int;
+    pub fn chip_detect_batch(n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, kind: *mut i32, stream: *mut c_void) -> c_int;
 
     pub fn chip_encoder_new(opts: *const chip_encoder_opts) -> *mut chip_encoder;
     pub fn chip_encode(e: *mut chip_encoder, input: *const u8, input_len: usize, output: *mut u8, output_len: usize, op: c_int) -> chip_encode_result;
     pub fn chip_encoder_reset(e: *mut chip_encoder) -> *mut chip_encoder;
     pub fn chip_encoder_free(e: *mut chip_encoder);
+    pub fn chip_encode_batch_ex(format: c_int, level: c_int, strategy: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32,
+                                out_base: *mut c_void, out_off: *const u64, out_cap: *const u32, out_len: *mut u32, status: *mut i32,
+                                stream: *mut c_void) -> c_int;
+    pub fn chip_encode_batch(format: c_int, level: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32,
+                             out_base: *mut c_void, out_off: *const u64, out_cap: *const u32, out_len: *mut u32, status: *mut i32,
+                             stream: *mut c_void) -> c_int;
+    pub fn chip_encode_bound(format: c_int, in_len: usize) -> usize;
+    pub fn chip_encode_batch_host(format: c_int, level: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32,
+                                  out_base: *mut c_void, out_off: *const u64, out_cap: *const u32, out_len: *mut u32, status: *mut i32, device: c_int,
+                                  slice_bytes: usize) -> c_int;
 }

@@ -30,6 +30,58 @@ def test_library_exports_every_declared_symbol():
     assert lib.chip_encode_bound(31, 65536) >= 65536 + 18
 
 
+def _c_prototypes():
+    """{name: number of parameters} of every function prototype in include/compu_hip.h."""
+    text = open(os.path.join(ROOT, "include", "compu_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(chip_[a-z0-9_]+)\s*\(([^;{}]*?)\)\s*;", text, flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        if name in ("chip_malloc_fn", "chip_free_fn"):
+            continue
+        protos[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return protos
+
+
+def _rust_externs():
+    """{name: number of parameters} of every `pub fn` in the extern block of integration/src/hip_sys.rs."""
+    text = open(os.path.join(ROOT, "integration", "src", "hip_sys.rs")).read()
+    text = re.sub(r"//[^\n]*", " ", text)
+    block = text[text.index('extern "C" {'):]
+    ext = {}
+    for m in re.finditer(r"pub fn (chip_[a-z0-9_]+)\s*\(([^;]*?)\)\s*(?:->[^;]*)?;", block, flags=re.S):
+        args = m.group(2).strip()
+        # a parameter is `name: type`; commas inside `Option<fn(..)>` types do not occur in this file's extern block
+        ext[m.group(1)] = 0 if not args else len([a for a in args.split(",") if ":" in a])
+    return ext
+
+
+def test_rust_bindings_cover_the_header():
+    """The boundary a compu maintainer compiles against: every prototype of include/compu_hip.h has an `extern "C"` line in
+    integration/src/hip_sys.rs with the same number of parameters, every extern exists in the header, and the library exports
+    them all (a text check: this image has no Rust toolchain)."""
+    import compu_amd
+
+    protos, ext = _c_prototypes(), _rust_externs()
+    assert len(protos) >= 30
+    missing = sorted(set(protos) - set(ext))
+    assert not missing, f"declared in include/compu_hip.h but not bound in hip_sys.rs: {missing}"
+    stray = sorted(set(ext) - set(protos))
+    assert not stray, f"bound in hip_sys.rs but not declared in include/compu_hip.h: {stray}"
+    for name, n in protos.items():
+        assert ext[name] == n, f"{name}: {n} parameters in the header, {ext[name]} in hip_sys.rs"
+    lib = compu_amd.lib()
+    for name in ext:
+        assert hasattr(lib, name), f"{name} bound in hip_sys.rs but not exported by the library"
+    # the hot path has safe faces next to the vtables
+    dec = open(os.path.join(ROOT, "integration", "src", "decoder", "hip.rs")).read()
+    enc = open(os.path.join(ROOT, "integration", "src", "encoder", "hip.rs")).read()
+    for fn in ("decode_batch_host", "decode_batch_multi", "decode_batch_device", "detect_batch_device", "partition_units"):
+        assert f"pub fn {fn}" in dec or f"pub unsafe fn {fn}" in dec, fn
+    for fn in ("encode_batch_host", "encode_batch_device", "encode_bound"):
+        assert f"pub fn {fn}" in enc or f"pub unsafe fn {fn}" in enc, fn
+
+
 def test_encode_bound_covers_what_the_oracle_encoder_writes():
     """chip_encode_bound is the capacity that is always enough: worst cases of every level (incompressible input: stored
     blocks at level 0 / 1, a stored block per 65 472 tokens at the dynamic levels) through the oracle encoder."""
