@@ -56,6 +56,20 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+class stdout_to_stderr:
+    """gloo announces its connections on the C-level stdout; rank 0's stdout must carry the one JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def make_workload(kind, payload, n_units, threads, first_unit=0):
     from bench_support import synth
 
@@ -317,7 +331,7 @@ def self_launch(n_gpus):
     import torch
 
     visible = torch.cuda.device_count()  # does not initialise the GPU on this image
-    if visible < n_gpus:
+    if visible < n_gpus and "BENCH_DEVICE_OVERRIDE" not in os.environ:  # (the rehearsal knob puts every rank on one named device)
         log(f"[bench] error: --gpus {n_gpus} but only {visible} GPU(s) are visible on this node")
         return 2
     with socket.socket() as sk:
@@ -379,10 +393,12 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
 
-        if backend == "nccl":
-            dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist_mod.init_process_group(backend=backend)
+        with stdout_to_stderr():
+            if backend == "nccl":
+                dist_mod.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist_mod.init_process_group(backend=backend)
+            dist_mod.barrier()  # (the connections are made, and announced, at the first collective)
         dist = dist_mod
     compu_amd.lib().chip_set_device(local_rank)
 
