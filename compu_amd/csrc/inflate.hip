@@ -122,8 +122,8 @@ __device__ __forceinline__ uint32_t make_dist16(uint32_t sym, uint32_t len)
 // the 64 lanes' first window reads hit distinct LDS banks.
 #ifndef CHIP_S_BITS  // geometry overridable for experiments
 #define CHIP_S_BITS 384
-#define CHIP_XT_BITS 1024
-#define CHIP_XT_BITS_FIXED 2048  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
+#define CHIP_XT_BITS 1536
+#define CHIP_XT_BITS_FIXED 3072  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
 #define CHIP_ROW_TOKENS 256
 #endif
 constexpr uint32_t S_BITS = CHIP_S_BITS;

@@ -204,7 +204,7 @@ def test_deep_huffman_codes_use_the_subtables(gpu):
             caps.append(len(pay))
             want.append(pay)
     outs, ol, iu, st = run_batch(torch, -15, parts, caps)
-    ref = oracle_batch(0, parts, caps)
+    ref = oracle_batch(-15, parts, caps)
     for i in range(len(parts)):
         assert st[i] == ref[i][2] == 2, (i, st[i], ref[i][2])
         assert outs[i] == want[i] == ref[i][0], f"stream {i} differs"
