@@ -166,7 +166,7 @@ struct HuffMeta {
 
 // LZ77 execution state of a chunk (see below)
 #ifndef CHIP_CHUNK_BYTES
-#define CHIP_CHUNK_BYTES 2560
+#define CHIP_CHUNK_BYTES 3584
 #endif
 #ifndef CHIP_COPY_LANE_MAX
 #define CHIP_COPY_LANE_MAX 32

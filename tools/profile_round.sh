@@ -1,22 +1,17 @@
 #!/bin/bash
-# Round profile recipe (GPU box): kernel trace of the default bench, then FETCH_SIZE / WRITE_SIZE in their own
-# passes (never combined with other trace domains) -- for the default (dynamic-Huffman) workload, whose run also covers
-# the stored and fixed variants, and for the mixed gzip+zstd (chip::zstd_kernel) and encode (chip::deflate_kernel)
-# workloads.  Outputs land under gpurun_out/; tools/profiles_summarize.py turns them into the files kept under profiles/.
+# Round profile recipe (GPU box): kernel trace + stats of the default bench (which covers every BASELINE config), then, per
+# workload, FETCH_SIZE / WRITE_SIZE in passes of their own (never combined with other trace domains), then the instruction
+# counters of the inflate kernel.  Outputs land under gpurun_out/; tools/profiles_summarize.py turns them into the files kept
+# under profiles/.
 #   usage: bash tools/profile_round.sh <tag>
 set -eo pipefail
-tag="${1:-r02}"
+tag="${1:-r03}"
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT"
 make -s -C oracle
 rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_kt -o run --output-format csv -- python3 bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.log
 echo "[profile] default bench traced"
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_pmc_fetch -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> gpurun_out/${tag}_pmc_fetch.log
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_pmc_write -o run --output-format csv -- python3 bench.py --steps 3 --warmup 1 --no-cpu > /dev/null 2> gpurun_out/${tag}_pmc_write.log
-echo "[profile] default PMC passes done"
-for wl in mixed encode; do
-  rocprofv3 --kernel-trace --stats -d gpurun_out/${tag}_${wl}_kt -o run --output-format csv -- python3 bench.py --workload $wl --steps 5 --warmup 2 --no-cpu --extra 0 > gpurun_out/${tag}_${wl}.json 2>> gpurun_out/${tag}_bench.log
-  echo "[profile] $wl traced"
+for wl in dynamic stored fixed mixed encode; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_${wl}_pmc_fetch -o run --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --extra 0 > /dev/null 2>> gpurun_out/${tag}_bench.log
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/${tag}_${wl}_pmc_write -o run --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --extra 0 > /dev/null 2>> gpurun_out/${tag}_bench.log
   echo "[profile] $wl PMC passes done"
