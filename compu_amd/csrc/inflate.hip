@@ -785,7 +785,7 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, base));
         const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)pdelta);
         uint32_t t = g + lane;
-        t = t < ntok ? t : ntok - 1u;
+        if (g + 64u > ntok) t = t < ntok ? t : ntok - 1u;  // (uniform: the batch's last group)
         before += inside;
         gnext = g + 64u;
         const uint32_t krow = (t + d) & 0xffffu;  // the token's index in its lane's row
@@ -839,7 +839,8 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         uint32_t nacc;
         bool ending, too_far = false;
         // The common group: 64 tokens that all fit the chunk, no distance reaching in front of the output's first byte.
-        if (left >= 64u && run + total <= CHUNK_BYTES && !__any(len != 0 && val > prod0 + start)) {
+        // (a distance cannot reach in front of the output once 32 KiB of it exist)
+        if (left >= 64u && run + total <= CHUNK_BYTES && (prod0 >= 32768u || !__any(len != 0 && val > prod0 + start))) {
             asm volatile("; the common group" ::: "memory");  // (keeps the compiler from folding this path into the general one below)
             if (len == 0) img[start] = (uint8_t)val;
             else {
