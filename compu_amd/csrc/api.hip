@@ -765,7 +765,6 @@ bool dec_run(chip_decoder *d)
         d->d_in_len = in_len;
     }
     const bool inflate = d->format != CHIP_FMT_ZSTD;
-    constexpr size_t ZRES_BYTES = (16 + 2312) * 4 + 64;  // zstd.hip: ZRES_HDR + ZSAVE_WORDS
     if (!inflate && !d->d_zres) {
         d->d_zres = (uint32_t *)chip_device_alloc(ZRES_BYTES);
         if (!d->d_zres || hipMemsetAsync(d->d_zres, 0, 64, d->stream) != hipSuccess) return false;
@@ -1003,7 +1002,7 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
 void chip_decoder_footprint(const chip_decoder *d, size_t *pinned_bytes, size_t *device_bytes)
 {
     if (pinned_bytes) *pinned_bytes = d ? d->h_in_cap + sizeof(Meta) : 0;
-    if (device_bytes) *device_bytes = d ? d->d_in_cap + d->d_out_cap + sizeof(Meta) + (d->d_zres ? (16 + 2312) * 4 + 64 : 0) : 0;
+    if (device_bytes) *device_bytes = d ? d->d_in_cap + d->d_out_cap + sizeof(Meta) + (d->d_zres ? ZRES_BYTES : 0) : 0;
 }
 
 chip_decoder *chip_decoder_reset(chip_decoder *d)

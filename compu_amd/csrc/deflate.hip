@@ -960,12 +960,12 @@ struct EncSlot {
 std::mutex g_enc_mu;
 std::map<std::pair<int, hipStream_t>, EncSlot> g_enc_slots;
 
+// (caller holds g_enc_mu)
 hipError_t enc_slot_for(hipStream_t stream, uint32_t n, EncSlot &out)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(g_enc_mu);
     EncSlot &sl = g_enc_slots[{dev, stream}];
     static int max_blocks[64] = {0};
     const int di = dev < 64 ? dev : 63;
@@ -1038,12 +1038,12 @@ hipError_t launch_deflate_l1(const BatchArgs &b, int level, uint32_t flags, uint
     a.check_out = check_out;
     const uint32_t strategy = (flags >> 8) & 7u;
     if (level >= 2 && strategy != CHIP_STRATEGY_FIXED) {
+        // One lock from the slot's lookup to the launch (as launch_inflate): another host thread launching a larger batch on the same
+        // stream may free and reallocate the scratch in enc_slot_for(); the counter reset and the kernel reach the stream back to back.
+        std::lock_guard<std::mutex> lk(g_enc_mu);
         EncSlot sl;
         hipError_t e = enc_slot_for(stream, b.n, sl);
         if (e != hipSuccess) return e;
-        // counter reset and kernel must reach the stream back to back even when several host threads launch on it
-        static std::mutex enqueue_mu;
-        std::lock_guard<std::mutex> lk(enqueue_mu);
         if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
         const uint32_t blocks = b.n < (uint32_t)sl.blocks ? b.n : (uint32_t)sl.blocks;
         hipLaunchKernelGGL(deflate_dyn_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);

@@ -68,8 +68,7 @@ struct alignas(16) ZLds {
 // ([0] 1 + input bytes consumed (0 = none), [1] output bytes, [2..4] repeat offsets, [5] flags: 1 checksum, 2 content size
 // known, 4 all blocks done, [6,7] content size, [8,9] window, [10,11] output limit) followed by the LDS image of the
 // Huffman and FSE tables, which later blocks may reuse (treeless literals, repeat modes).
-constexpr uint32_t ZSAVE_WORDS = 2312;  // ZLds up to `weights`
-constexpr uint32_t ZRES_HDR = 16;
+// (ZSAVE_WORDS, ZRES_HDR: chip_internal.h -- the host side sizes the checkpoint from them)
 static_assert(offsetof(ZLds, weights) == ZSAVE_WORDS * 4, "checkpoint covers the decode tables");
 
 // the unit's input seen as dwords (aligned down), addressed by absolute bit index

@@ -1,5 +1,8 @@
 # PMC passes over the encoder kernel: bash tools/pmc_encode.sh [kind=encode] [tag=enc]   (on the GPU box, from the repo root)
-# (a third pass with TA_*/TCP_* counters hung the profiler on this pool and is not run)
+# (A third pass that asked for TA_*/TCP_* counters is not run: rocprofv3 aborted at the first dispatch, before any product kernel ran --
+# rocprofiler_create_counter_config, error 38 "Request exceeds the capabilities of the hardware to collect", i.e. more TA/TCP counters than
+# one pass can hold (round 2's gpurun_out/encC.log).  Those counters are not collected; the candidate-load amplification is read off the
+# ISA and FETCH_SIZE instead.)
 kind=${1:-encode}; tag=${2:-enc}
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
