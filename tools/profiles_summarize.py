@@ -79,4 +79,6 @@ if os.path.exists(os.path.join(G, f"{tag}_pmc_insts.txt")):
     open(os.path.join(P, f"{tag}_pmc_insts.txt"), "w").write(open(os.path.join(G, f"{tag}_pmc_insts.txt")).read())
 if os.path.exists(os.path.join(G, f"{tag}_bench.json")):
     open(os.path.join(P, f"{tag}_bench_rocprof_run.json"), "w").write(open(os.path.join(G, f"{tag}_bench.json")).read())
+if os.path.exists(os.path.join(G, f"{tag}_mixed_131072.json")):
+    open(os.path.join(P, f"{tag}_bench_mixed_131072_units.json"), "w").write(open(os.path.join(G, f"{tag}_mixed_131072.json")).read())
 print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in out.items() if isinstance(v, dict)}))
