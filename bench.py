@@ -528,10 +528,12 @@ def main():
         try:
             with open(traffic_file) as f:
                 tr = json.load(f)
-            line["roofline"]["traffic"] = tr.get(args.workload, {}).get("hbm_bytes_per_launch")
+            # the counters were taken on launches of 65 536 units: a launch of another size has no measured figure
+            same = args.units == 65536
+            line["roofline"]["traffic"] = tr.get(args.workload, {}).get("hbm_bytes_per_launch") if same else None
             line["roofline"]["traffic_source"] = tr.get("source")
             for k in line["workloads"]:
-                line["workloads"][k]["traffic"] = tr.get(k, {}).get("hbm_bytes_per_launch")
+                line["workloads"][k]["traffic"] = tr.get(k, {}).get("hbm_bytes_per_launch") if same else None
         except Exception:
             pass
     print(json.dumps(line), flush=True)

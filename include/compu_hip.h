@@ -94,8 +94,8 @@ void chip_pinned_free(void *ptr);
 int chip_memcpy_h2d(void *dst_dev, const void *src_host, size_t size, void *stream);
 int chip_memcpy_d2h(void *dst_host, const void *src_dev, size_t size, void *stream);
 int chip_stream_sync(void *stream);
-/* The inflate kernel keeps a token scratch per (device, stream) it has been launched on: one 48 KiB slot per
- * resident wave, about 200 MB on an MI355X, allocated at the first launch and reused.  chip_trim() waits for the
+/* The inflate kernel keeps a token scratch per (device, stream) it has been launched on: one 64 KiB slot per
+ * resident wave, about 270 MB on an MI355X, allocated at the first launch and reused.  chip_trim() waits for the
  * current device and gives that memory back (the next launch allocates again).  No reference counterpart:
  * zlib-ng's inflate state is ~40 KiB of host memory per decoder (src/decoder/zlib_ng.rs:29-55). */
 int chip_trim(void);
@@ -126,7 +126,7 @@ void chip_decoder_free(chip_decoder *d);
 /* Memory a streaming decoder holds right now: pinned host bytes (buffered input) and device bytes (input copy, decoded
  * output not yet handed on + the 32 KiB window, checkpoint).  An inflate stream keeps O(window + piece) whatever its
  * length: input in front of the last block boundary and output that has been handed on are dropped between calls (the
- * reference's state is ~40 KiB per decoder, src/decoder/zlib_ng.rs:29-55).  The kernel's token scratch (48 KiB per
+ * reference's state is ~40 KiB per decoder, src/decoder/zlib_ng.rs:29-55).  The kernel's token scratch (64 KiB per
  * streaming decoder) is not included. */
 void chip_decoder_footprint(const chip_decoder *d, size_t *pinned_bytes, size_t *device_bytes);
 /* describe_error_fn: src/decoder/zlib_ng.rs:118-123 (zError), src/decoder/zstd.rs:159-164
