@@ -716,6 +716,7 @@ struct chip_decoder {
     size_t in_dropped;    // input bytes dropped in front of the buffer so far
     uint32_t last_ck;     // resume[0] + 8 * input bytes dropped so far: tells whether a run reached a new block boundary
     uint32_t *d_zres;     // zstd: device blob with the kernel's block checkpoint (header + decode tables), see zstd.hip
+    uint32_t *h_zhdr;     // zstd: host copy of the checkpoint's ZRES_HDR header words (pinned, behind h_meta)
 };
 
 namespace {
@@ -767,7 +768,7 @@ bool dec_run(chip_decoder *d)
     const bool inflate = d->format != CHIP_FMT_ZSTD;
     if (!inflate && !d->d_zres) {
         d->d_zres = (uint32_t *)chip_device_alloc(ZRES_BYTES);
-        if (!d->d_zres || hipMemsetAsync(d->d_zres, 0, 64, d->stream) != hipSuccess) return false;
+        if (!d->d_zres || hipMemsetAsync(d->d_zres, 0, ZRES_HDR * 4, d->stream) != hipSuccess) return false;
     }
     size_t cap = d->d_out_cap;
     if (cap == 0) cap = in_len * 4 > 65536 ? in_len * 4 : 65536;
@@ -805,18 +806,21 @@ bool dec_run(chip_decoder *d)
         hipError_t e = inflate ? launch_inflate(a, d->stream) : launch_zstd_decode(a, d->window_log_max, d->stream);
         if (e != hipSuccess) return false;
         if (hipMemcpyAsync(d->h_meta, d->d_meta, sizeof(Meta), hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;
+        if (!inflate && hipMemcpyAsync(d->h_zhdr, d->d_zres, ZRES_HDR * 4, hipMemcpyDeviceToHost, d->stream) != hipSuccess) return false;
         if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
-        bool progress = true;
+        uint32_t ck;
         if (inflate) {
             for (uint32_t k = 0; k < RESUME_WORDS; k++) d->resume[k] = d->h_meta->resume[k];
-            const uint32_t ck = d->resume[0] + 8u * (uint32_t)d->in_dropped;
-            progress = ck != d->last_ck || d->h_meta->out_len > d->delivered;  // a new block boundary, or bytes to hand on
-            d->last_ck = ck;
+            ck = d->resume[0] + 8u * (uint32_t)d->in_dropped;
+        } else {
+            ck = d->h_zhdr[0] + (uint32_t)d->in_dropped;
         }
+        const bool progress = ck != d->last_ck || d->h_meta->out_len > d->delivered;  // a new block boundary, or bytes to hand on
+        d->last_ck = ck;
         d->k_out_len = d->h_meta->out_len;
-        // out of device output: a zstd frame is decoded in one piece (grow); an inflate stream that got somewhere hands
-        // on what it has and continues from its last boundary in a buffer of the same size
-        if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < DEC_OUT_LIMIT && (!inflate || !progress || d->d_out_cap < DEC_OUT_SOFT)) {
+        // out of device output: a stream that got somewhere hands on what it has and continues from its last boundary in a
+        // buffer of the same size; one that did not (a block, or a zstd window, larger than the buffer) gets a larger one
+        if (d->h_meta->status == CHIP_NEED_OUTPUT && d->d_out_cap < DEC_OUT_LIMIT && (!progress || d->d_out_cap < DEC_OUT_SOFT)) {
             cap = d->d_out_cap * 2;
             continue;
         }
@@ -828,12 +832,68 @@ bool dec_run(chip_decoder *d)
     return true;
 }
 
-// Between calls of an inflate stream that goes on: drop the input in front of the last block boundary and the output in
-// front of the 32 KiB window of that boundary that has been handed on (BatchArgs::resume says how the kernel is told).
+// Forward move of d_out[from .. from + n) to d_out[0 .. n), in pieces no longer than the distance: source and destination of a
+// piece never overlap.
+bool dec_move_down(chip_decoder *d, size_t from, size_t n)
+{
+    for (size_t done = 0; done < n;) {
+        const size_t c = n - done < from ? n - done : from;
+        if (hipMemcpyAsync(d->d_out + done, d->d_out + from + done, c, hipMemcpyDeviceToDevice, d->stream) != hipSuccess) return false;
+        done += c;
+    }
+    return hipStreamSynchronize(d->stream) == hipSuccess;
+}
+
+// Between calls of a stream that goes on: drop the input in front of the last block boundary and the output that has been
+// handed on and that no later block can reach -- inflate: in front of the 32 KiB window of that boundary (BatchArgs::resume
+// says how the kernel is told); zstd: in front of the frame's window, and never behind what the running XXH64 covers (the
+// checkpoint header, zstd.hip).  A single-segment zstd frame's window is its content size: nothing is dropped for it, as libzstd
+// keeps it whole (src/decoder/zstd.rs:98-136 sits on ZSTD_decompressStream).
 bool dec_compact(chip_decoder *d)
 {
-    if (d->format == CHIP_FMT_ZSTD || !d->decoded) return true;
+    if (!d->decoded) return true;
     if (d->k_status != CHIP_NEED_INPUT && d->k_status != CHIP_NEED_OUTPUT) return true;
+    if (d->format == CHIP_FMT_ZSTD) {
+        uint32_t *zh = d->h_zhdr;
+        if (zh[0] == 0) return true;  // no block done yet
+        bool dirty = false;
+        const size_t drop_in = ((size_t)zh[0] - 1u) & ~(size_t)3;  // the boundary's byte, dword aligned down
+        if (drop_in >= DEC_DROP_IN) {
+            memmove(d->h_in, d->h_in + drop_in, d->h_in_len - drop_in);
+            d->h_in_len -= drop_in;
+            d->d_in_len = 0;  // the (short) rest is uploaded again
+            zh[0] -= (uint32_t)drop_in;
+            d->in_dropped += drop_in;
+            d->k_in_used = d->k_in_used > drop_in ? d->k_in_used - (uint32_t)drop_in : 0;
+            dirty = true;
+        }
+        const uint64_t window = (uint64_t)zh[8] | ((uint64_t)zh[9] << 32);
+        const uint64_t dropped = (uint64_t)zh[12] | ((uint64_t)zh[13] << 32);
+        const size_t r1 = zh[1];
+        size_t keep_from = r1 > window ? r1 - (size_t)window : 0;
+        if (keep_from > d->delivered) keep_from = d->delivered;
+        if (zh[5] & 1u) {  // content checksum: bytes the running hash has not taken yet stay
+            const uint64_t hashed = (uint64_t)zh[14] | ((uint64_t)zh[15] << 32);
+            const size_t hrel = (size_t)(hashed - dropped);
+            if (keep_from > hrel) keep_from = hrel;
+        }
+        keep_from &= ~(size_t)15;
+        if (keep_from >= DEC_DROP_OUT) {
+            if (!dec_move_down(d, keep_from, d->k_out_len - keep_from)) return false;
+            d->delivered -= keep_from;
+            d->k_out_len -= (uint32_t)keep_from;
+            zh[1] -= (uint32_t)keep_from;
+            const uint64_t nd = dropped + keep_from;
+            zh[12] = (uint32_t)nd;
+            zh[13] = (uint32_t)(nd >> 32);
+            dirty = true;
+        }
+        if (dirty) {
+            if (hipMemcpyAsync(d->d_zres, zh, ZRES_HDR * 4, hipMemcpyHostToDevice, d->stream) != hipSuccess) return false;
+            if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
+        }
+        return true;
+    }
     const uint32_t r0 = d->resume[0], r1 = d->resume[1];
     if (r0 == 0) return true;
     const size_t bnd = r0 >> 3;  // the boundary's byte; 8 bytes stay in front of it so that the offset never becomes 0
@@ -849,13 +909,7 @@ bool dec_compact(chip_decoder *d)
     size_t keep_from = d->delivered < r1 ? d->delivered : r1;
     keep_from = keep_from > 32768 ? ((keep_from - 32768) & ~(size_t)15) : 0;
     if (keep_from >= DEC_DROP_OUT) {
-        const size_t n = d->k_out_len - keep_from;
-        for (size_t done = 0; done < n;) {  // forward, in pieces no longer than the distance: source and destination never overlap
-            const size_t c = n - done < keep_from ? n - done : keep_from;
-            if (hipMemcpyAsync(d->d_out + done, d->d_out + keep_from + done, c, hipMemcpyDeviceToDevice, d->stream) != hipSuccess) return false;
-            done += c;
-        }
-        if (hipStreamSynchronize(d->stream) != hipSuccess) return false;
+        if (!dec_move_down(d, keep_from, d->k_out_len - keep_from)) return false;
         d->delivered -= keep_from;
         d->k_out_len -= (uint32_t)keep_from;
         d->resume[1] -= (uint32_t)keep_from;
@@ -876,8 +930,9 @@ void dec_clear(chip_decoder *d)
     for (uint32_t k = 0; k < RESUME_WORDS; k++) d->resume[k] = 0;
     d->last_ck = 0;
     d->in_dropped = 0;
+    if (d->h_zhdr) memset(d->h_zhdr, 0, ZRES_HDR * 4);
     if (d->d_zres) {  // the next stream starts from its frame header
-        (void)hipMemsetAsync(d->d_zres, 0, 64, d->stream);
+        (void)hipMemsetAsync(d->d_zres, 0, ZRES_HDR * 4, d->stream);
         (void)hipStreamSynchronize(d->stream);
     }
 }
@@ -909,7 +964,8 @@ chip_decoder *chip_decoder_new(int format, const chip_decoder_opts *opts)
         return nullptr;
     }
     d->d_meta = (Meta *)chip_device_alloc(sizeof(Meta));
-    d->h_meta = (Meta *)chip_pinned_alloc(sizeof(Meta));
+    d->h_meta = (Meta *)chip_pinned_alloc(sizeof(Meta) + ZRES_HDR * 4);
+    d->h_zhdr = d->h_meta ? (uint32_t *)(d->h_meta + 1) : nullptr;
     if (!d->d_meta || !d->h_meta || !dec_reserve_in(d, 65536)) {
         chip_decoder_free(d);
         return nullptr;
@@ -962,10 +1018,11 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
             n_total += n;
         }
         // everything decoded so far is handed on but the device buffer was the limit: make room and decode on
-        if (d->delivered == d->k_out_len && d->k_status == CHIP_NEED_OUTPUT && d->format != CHIP_FMT_ZSTD && n_total < out_len) {
-            const uint32_t before = d->resume[1];
+        if (d->delivered == d->k_out_len && d->k_status == CHIP_NEED_OUTPUT && n_total < out_len) {
+            const bool zs = d->format == CHIP_FMT_ZSTD;
+            const uint32_t before = zs ? d->h_zhdr[1] : d->resume[1];
             if (!dec_compact(d)) return fail(-4);
-            if (d->resume[1] == before && d->d_out_cap >= DEC_OUT_LIMIT) break;  // nothing could be dropped and nothing can grow
+            if ((zs ? d->h_zhdr[1] : d->resume[1]) == before && d->d_out_cap >= DEC_OUT_LIMIT) break;  // nothing could be dropped and nothing can grow
             d->decoded = false;
             continue;
         }
@@ -1001,7 +1058,7 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
 
 void chip_decoder_footprint(const chip_decoder *d, size_t *pinned_bytes, size_t *device_bytes)
 {
-    if (pinned_bytes) *pinned_bytes = d ? d->h_in_cap + sizeof(Meta) : 0;
+    if (pinned_bytes) *pinned_bytes = d ? d->h_in_cap + sizeof(Meta) + ZRES_HDR * 4 : 0;
     if (device_bytes) *device_bytes = d ? d->d_in_cap + d->d_out_cap + sizeof(Meta) + (d->d_zres ? ZRES_BYTES : 0) : 0;
 }
 

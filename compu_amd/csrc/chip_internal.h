@@ -28,7 +28,7 @@ constexpr uint32_t RESUME_WORDS = 6;
 
 // The streaming zstd decoder's checkpoint in device memory (written by zstd_kernel, sized by api.hip): a header of ZRES_HDR words, then the
 // first ZSAVE_WORDS words of the kernel's LDS state (its decode tables; zstd.hip asserts that this is where `weights` starts), then slack.
-constexpr uint32_t ZRES_HDR = 16;
+constexpr uint32_t ZRES_HDR = 24;
 constexpr uint32_t ZSAVE_WORDS = 2312;
 constexpr size_t ZRES_BYTES = (size_t)(ZRES_HDR + ZSAVE_WORDS) * 4 + 64;
 

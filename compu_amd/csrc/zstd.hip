@@ -64,10 +64,13 @@ struct alignas(16) ZLds {
     uint32_t xpar[192];    // copy phase: per-item parameters
 };
 
-// Streaming decoder only (BatchArgs::resume, one unit): checkpoint written after every completed block -- 16 header words
-// ([0] 1 + input bytes consumed (0 = none), [1] output bytes, [2..4] repeat offsets, [5] flags: 1 checksum, 2 content size
-// known, 4 all blocks done, [6,7] content size, [8,9] window, [10,11] output limit) followed by the LDS image of the
-// Huffman and FSE tables, which later blocks may reuse (treeless literals, repeat modes).
+// Streaming decoder only (BatchArgs::resume, one unit): checkpoint written after every completed block -- ZRES_HDR header words
+// ([0] 1 + input bytes consumed (0 = none), [1] output bytes in the buffer, [2..4] repeat offsets, [5] flags: 1 checksum, 2 content
+// size known, 4 all blocks done, [6,7] content size, [8,9] window, [10,11] output limit, [12,13] output bytes the HOST has dropped
+// in front of the buffer (written by the host only), [14,15] output bytes the running XXH64 covers (a multiple of 32, counted from
+// the frame's start), [16..23] its four accumulators) followed by the LDS image of the Huffman and FSE tables, which later blocks may
+// reuse (treeless literals, repeat modes).  Between calls the host may drop input in front of [0] and output in front of
+// min([1] - window, [14,15]) -- api.hip -- so a long frame is decoded in O(window) memory.
 // (ZSAVE_WORDS, ZRES_HDR: chip_internal.h -- the host side sizes the checkpoint from them)
 static_assert(offsetof(ZLds, weights) == ZSAVE_WORDS * 4, "checkpoint covers the decode tables");
 
@@ -700,54 +703,72 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
     return (int)used;
 }
 
-// XXH64 (seed 0) of p[0..n): lanes 0..3 own the four accumulators.  Returns the low 32 bits.
-// `stage`: 512 qwords of LDS scratch (anything that is dead once the frame's blocks are done).
-__device__ uint32_t wave_xxh64_low32(uint64_t *stage, const uint8_t *p, uint32_t n)
+// XXH64 (seed 0), lanes 0..3 own the four accumulators.  Three steps so that the streaming decoder can carry the state
+// from block to block: xxh_init(), xxh_stripes() over whole 32-byte stripes, xxh_finish() with the bytes behind the last stripe.
+// `stage`: 4 * stage_stripes qwords of LDS scratch.
+__device__ __forceinline__ uint64_t xxh_init()
+{
+    constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL;
+    const uint32_t lane = lane_id();
+    return lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ULL : 0ULL - P1;
+}
+
+struct XxhView {  // aligned dword view of a byte range; reads stay inside dwords that hold bytes of it
+    const uint32_t *p32;
+    uint32_t pmis;
+    __device__ __forceinline__ explicit XxhView(const uint8_t *p) : p32((const uint32_t *)(p - ((uintptr_t)p & 3u))), pmis((uint32_t)((uintptr_t)p & 3u)) {}
+    __device__ __forceinline__ uint64_t rd64(uint32_t off) const
+    {
+        const uint32_t i = (pmis + off) >> 2, sh = ((pmis + off) & 3u) * 8u;
+        const uint32_t d0 = p32[i], d1 = p32[i + 1], d2 = sh ? p32[i + 2] : 0u;
+        return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
+    }
+};
+
+__device__ void xxh_stripes(uint64_t *stage, const uint32_t stage_stripes, const uint8_t *p, uint32_t stripes, uint64_t &acc)
+{
+    constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL;
+    auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
+    const XxhView V(p);
+    const uint32_t lane = lane_id();
+    // The accumulator recurrence acc = rotl(acc + in * P2, 31) * P1 is serial per 8-byte column, but the products
+    // in * P2 are not: all 64 lanes form them for up to 128 stripes at a time into `stage` (4 KB of LDS), then lanes 0..3
+    // run their columns over the staged products -- one multiplication per dependent step instead of two, and no
+    // address arithmetic or loads on the chain.
+    for (uint32_t s0 = 0; s0 < stripes; s0 += stage_stripes) {
+        const uint32_t ns = stripes - s0 < stage_stripes ? stripes - s0 : stage_stripes;
+        WSYNC();
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t q = 64u * k + lane;  // qword of the batch: stripe q / 4, column q % 4
+            if (q < 4u * ns) stage[q] = V.rd64(32u * s0 + 8u * q) * P2;
+        }
+        WSYNC();
+        if (lane < 4) {
+            uint32_t i = 0;
+            for (; i + 8 <= ns; i += 8) {
+                uint64_t in[8];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) in[k] = stage[4u * (i + k) + lane];
+#pragma unroll
+                for (uint32_t k = 0; k < 8; k++) acc = rotl(acc + in[k], 31) * P1;
+            }
+            for (; i < ns; i++) acc = rotl(acc + stage[4u * i + lane], 31) * P1;
+        }
+    }
+    WSYNC();
+}
+
+// total: bytes hashed altogether (stripes and tail); tail[0..tail_n): the bytes behind the last whole stripe (< 32).  Low 32 bits.
+__device__ uint32_t xxh_finish(uint64_t acc, uint64_t total, const uint8_t *tail, uint32_t tail_n)
 {
     constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL,
                        P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
     auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
-    const uint32_t pmis = (uint32_t)((uintptr_t)p & 3u);
-    const uint32_t *p32 = (const uint32_t *)(p - pmis);  // aligned view; reads stay inside dwords that hold bytes of p[0..n)
-    auto rd64 = [&](uint32_t off) {
-        const uint32_t i = (pmis + off) >> 2, sh = ((pmis + off) & 3u) * 8u;
-        const uint32_t d0 = p32[i], d1 = p32[i + 1], d2 = sh ? p32[i + 2] : 0u;
-        return (uint64_t)__builtin_amdgcn_alignbit(d1, d0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(d2, d1, sh) << 32);
-    };
-    auto round1 = [&](uint64_t acc, uint64_t in) { return rotl(acc + in * P2, 31) * P1; };
-    const uint32_t lane = lane_id();
+    auto round1 = [&](uint64_t a, uint64_t in) { return rotl(a + in * P2, 31) * P1; };
+    const XxhView V(tail);
     uint64_t h;
-    uint32_t off = 0;
-    if (n >= 32) {
-        uint64_t acc = lane == 0 ? P1 + P2 : lane == 1 ? P2 : lane == 2 ? 0ULL : 0ULL - P1;
-        const uint32_t stripes = n >> 5;
-        // The accumulator recurrence acc = rotl(acc + in * P2, 31) * P1 is serial per 8-byte column, but the products
-        // in * P2 are not: all 64 lanes form them for 128 stripes at a time into `stage` (4 KB of LDS), then lanes 0..3
-        // run their columns over the staged products -- one multiplication per dependent step instead of two, and no
-        // address arithmetic or loads on the chain.
-        for (uint32_t s0 = 0; s0 < stripes; s0 += 128) {
-            const uint32_t ns = stripes - s0 < 128 ? stripes - s0 : 128;
-            WSYNC();
-#pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint32_t q = 64u * k + lane;  // qword of the batch: stripe q / 4, column q % 4
-                if (q < 4u * ns) stage[q] = rd64(32u * s0 + 8u * q) * P2;
-            }
-            WSYNC();
-            if (lane < 4) {
-                uint32_t i = 0;
-                for (; i + 8 <= ns; i += 8) {
-                    uint64_t in[8];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) in[k] = stage[4u * (i + k) + lane];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8; k++) acc = rotl(acc + in[k], 31) * P1;
-                }
-                for (; i < ns; i++) acc = rotl(acc + stage[4u * i + lane], 31) * P1;
-            }
-        }
-        WSYNC();
-        off = stripes << 5;
+    if (total >= 32) {
         uint64_t v[4];
         for (int k = 0; k < 4; k++) {
             uint32_t lo = rdlane((uint32_t)acc, (uint32_t)k), hi = rdlane((uint32_t)(acc >> 32), (uint32_t)k);
@@ -758,21 +779,22 @@ __device__ uint32_t wave_xxh64_low32(uint64_t *stage, const uint8_t *p, uint32_t
     } else {
         h = P5;
     }
-    h += (uint64_t)n;
-    while (off + 8 <= n) {
-        h ^= round1(0, rd64(off));
+    h += total;
+    uint32_t off = 0;
+    while (off + 8 <= tail_n) {
+        h ^= round1(0, V.rd64(off));
         h = rotl(h, 27) * P1 + P4;
         off += 8;
     }
-    if (off + 4 <= n) {
+    if (off + 4 <= tail_n) {
         uint64_t v = 0;
-        for (int k = 3; k >= 0; k--) v = (v << 8) | p[off + (uint32_t)k];
+        for (int k = 3; k >= 0; k--) v = (v << 8) | tail[off + (uint32_t)k];
         h ^= v * P1;
         h = rotl(h, 23) * P2 + P3;
         off += 4;
     }
-    while (off < n) {
-        h ^= (uint64_t)p[off] * P5;
+    while (off < tail_n) {
+        h ^= (uint64_t)tail[off] * P5;
         h = rotl(h, 11) * P1;
         off++;
     }
@@ -782,6 +804,15 @@ __device__ uint32_t wave_xxh64_low32(uint64_t *stage, const uint8_t *p, uint32_t
     h *= P3;
     h ^= h >> 32;
     return (uint32_t)h;
+}
+
+// XXH64 (seed 0) of p[0..n) in one go.  `stage`: 512 qwords of LDS scratch (anything that is dead once the frame's blocks are done).
+__device__ uint32_t wave_xxh64_low32(uint64_t *stage, const uint8_t *p, uint32_t n)
+{
+    uint64_t acc = xxh_init();
+    const uint32_t stripes = n >> 5;
+    if (stripes) xxh_stripes(stage, 128, p, stripes, acc);
+    return xxh_finish(acc, n, p + (stripes << 5), n & 31u);
 }
 
 // wave-cooperative forward copy of n bytes; dst and src may overlap with dst - src = period >= 1
@@ -859,6 +890,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
 
     uint32_t *const rs = a.resume;  // streaming decoder: checkpoint blob of this (single) unit, else nullptr
     bool resumed = false, blocks_done = false;
+    // output bytes of this frame that the host has dropped in front of gout (streaming only): positions compared with the
+    // frame's content size or output limit count them, offsets can only reach what is still there
+    const uint64_t dropped = rs ? (uint64_t)rs[12] | ((uint64_t)rs[13] << 32) : 0ull;
     if (rs && rs[0] != 0 && rs[0] - 1u <= in_len && rs[1] <= cap) {
         resumed = true;
         ip = B0 + rs[0] - 1u;
@@ -875,9 +909,40 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         for (uint32_t k = lane; k < ZSAVE_WORDS; k += 64) ((uint32_t *)&L)[k] = rs[ZRES_HDR + k];
         WSYNC();
     }
+    if (rs && !resumed) {  // the running checksum starts with the frame
+        const uint64_t acc0 = xxh_init();
+        if (lane < 4) {
+            rs[16 + 2 * lane] = (uint32_t)acc0;
+            rs[17 + 2 * lane] = (uint32_t)(acc0 >> 32);
+        }
+        if (lane == 0) rs[14] = rs[15] = 0;
+    }
+    // streaming: the running XXH64 is brought up to the last whole 32-byte stripe of the output (the host drops nothing behind it)
+    auto hash_upto_opos = [&](uint64_t *stage, uint32_t stage_stripes, uint64_t &acc, uint32_t &rel) {
+        const uint64_t hashed = (uint64_t)rs[14] | ((uint64_t)rs[15] << 32);
+        acc = lane < 4 ? (uint64_t)rs[16 + 2 * lane] | ((uint64_t)rs[17 + 2 * lane] << 32) : 0ull;
+        rel = (uint32_t)(hashed - dropped);
+        const uint32_t ns = (opos - rel) >> 5;
+        if (ns) xxh_stripes(stage, stage_stripes, gout + rel, ns, acc);
+        rel += ns << 5;
+        const uint64_t h2 = dropped + rel;
+        if (lane < 4) {
+            rs[16 + 2 * lane] = (uint32_t)acc;
+            rs[17 + 2 * lane] = (uint32_t)(acc >> 32);
+        }
+        if (lane == 0) {
+            rs[14] = (uint32_t)h2;
+            rs[15] = (uint32_t)(h2 >> 32);
+        }
+    };
     auto save_checkpoint = [&](bool all_done) {
         if (!rs) return;
         WSYNC();
+        if (has_checksum) {  // (between blocks the sequence window / copy parameters are dead: 48 stripes of staging)
+            uint64_t acc;
+            uint32_t rel;
+            hash_upto_opos((uint64_t *)&L.seqwin[(offsetof(ZLds, seqwin) & 4u) ? 1 : 0], 48, acc, rel);  // (qword aligned)
+        }
         for (uint32_t k = lane; k < ZSAVE_WORDS; k += 64) rs[ZRES_HDR + k] = ((const uint32_t *)&L)[k];
         if (lane == 0) {
             rs[1] = opos;
@@ -947,7 +1012,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         if (type == 3) ZFAIL(ZSTD_E_CORRUPTION);
         if (bsz > bmax) ZFAIL(ZSTD_E_CORRUPTION);
         if (type == 0) {  // raw block: streams through as far as the input goes
-            if ((uint64_t)opos + bsz > out_limit) ZFAIL(70);
+            if (dropped + opos + bsz > out_limit) ZFAIL(70);
             ip += 3;
             uint32_t avail = END - ip, k = bsz < avail ? bsz : avail;
             if (k > cap - opos) {
@@ -960,7 +1025,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
             if (k < bsz) ZNEED_INPUT();
         } else if (type == 1) {
             if (END - ip < 4) ZNEED_INPUT();
-            if ((uint64_t)opos + bsz > out_limit) ZFAIL(70);
+            if (dropped + opos + bsz > out_limit) ZFAIL(70);
             if (bsz > cap - opos) {
                 status = CHIP_NEED_OUTPUT;
                 goto done;
@@ -1483,7 +1548,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t fail = 0;
                     if (lane == dec_bad) fail = 5;
                     else if (lane < cn && lane < dec_bad) {
-                        if ((uint64_t)ostart + tot > out_limit || (uint64_t)(ostart - block_out0) + tot > BLOCK_MAX) fail = 1;
+                        if (dropped + ostart + tot > out_limit || (uint64_t)(ostart - block_out0) + tot > BLOCK_MAX) fail = 1;
                         else if (lit_incl > regen - lpos) fail = 2;
                         else if ((uint64_t)ostart + tot > cap) fail = 3;
                         else if (off > mstart) fail = 4;
@@ -1619,7 +1684,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 if (s.avail != (int32_t)s.used) ZFAIL(ZSTD_E_CORRUPTION);  // the bitstream must be consumed exactly
             }
             const uint32_t restl = regen - lpos;
-            if ((uint64_t)opos + restl > out_limit) ZFAIL(70);
+            if (dropped + opos + restl > out_limit) ZFAIL(70);
             if ((uint64_t)(opos - block_out0) + restl > BLOCK_MAX) ZFAIL(70);
             if ((uint64_t)opos + restl > cap) {
                 opos = block_out0;
@@ -1631,7 +1696,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
             ip = bend;
         }
         if (last) {
-            if (has_fcs && (uint64_t)opos != fcs) ZFAIL(ZSTD_E_CORRUPTION);
+            if (has_fcs && dropped + opos != fcs) ZFAIL(ZSTD_E_CORRUPTION);
             blocks_done = true;
         }
         save_checkpoint(blocks_done);
@@ -1640,7 +1705,16 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         if (END - ip < 4) ZNEED_INPUT();
         uint32_t want = rd32_at(b, ip * 8u);
 #ifndef CHIP_EXP_NOXXH
-        if (wave_xxh64_low32((uint64_t *)L.huf, gout, opos) != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);  // the Huffman table is dead by now
+        uint32_t got;
+        if (rs) {  // streaming: the state carried from block to block, then the bytes behind its last stripe
+            uint64_t acc;
+            uint32_t rel;
+            hash_upto_opos((uint64_t *)L.huf, 128, acc, rel);
+            got = xxh_finish(acc, dropped + opos, gout + rel, opos - rel);
+        } else {
+            got = wave_xxh64_low32((uint64_t *)L.huf, gout, opos);  // the Huffman table is dead by now
+        }
+        if (got != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);
 #endif
         ip += 4;
     }

@@ -239,3 +239,124 @@ def test_streaming_a_long_zstd_frame_in_small_pieces_is_linear(gpu, alice):
     o2 = bytearray(6000)
     r = dec.decode(small, o2)
     assert r.status == compu.DecodeStatus.Finished and bytes(o2[: len(o2) - r.output_remain]) == alice[:5000]
+
+
+def _compress_windowed(z, data, level, window_log, ldm=False, content_size=True):
+    """One frame with an explicit window (ZSTD_c_windowLog): larger inputs get a windowed, not a single-segment, frame."""
+    import ctypes as C
+
+    cctx = z.ZSTD_createCCtx()
+    z.ZSTD_CCtx_setParameter(cctx, 100, level)
+    z.ZSTD_CCtx_setParameter(cctx, 101, window_log)  # ZSTD_c_windowLog
+    z.ZSTD_CCtx_setParameter(cctx, 201, 1)  # ZSTD_c_checksumFlag
+    z.ZSTD_CCtx_setParameter(cctx, 200, 1 if content_size else 0)
+    if ldm:
+        z.ZSTD_CCtx_setParameter(cctx, 160, 1)  # ZSTD_c_enableLongDistanceMatching
+    cap = z.ZSTD_compressBound(len(data))
+    dst = (C.c_char * cap)()
+    src = (C.c_char * len(data)).from_buffer(data) if isinstance(data, bytearray) else C.create_string_buffer(bytes(data), len(data))
+    n = z.ZSTD_compress2(cctx, dst, cap, src, len(data))
+    z.ZSTD_freeCCtx(cctx)
+    assert not z.ZSTD_isError(n)
+    return bytes(memoryview(dst)[:n])
+
+
+def _stream_through(compu, dec, comp, piece, out_cap, gpu=None, every=64):
+    """compu's decode loop (src/decoder/mod.rs:323-335) over `comp`; -> (crc32 of the output, its length, peaks)"""
+    import zlib
+
+    out = bytearray(out_cap)
+    crc, got, pos, calls = 0, 0, 0, 0
+    peak_pin = peak_dev = 0
+    min_free = gpu.cuda.mem_get_info()[0] if gpu else 0
+    status = None
+    while status != compu.DecodeStatus.Finished:
+        chunk = comp[pos : pos + piece]
+        r = dec.decode(chunk, out)
+        assert r.is_ok(), (pos, r.status)
+        n = len(out) - r.output_remain
+        crc = zlib.crc32(memoryview(out)[:n], crc)
+        got += n
+        pos += len(chunk) - r.input_remain
+        status = r.status
+        calls += 1
+        if gpu and calls % every == 0:
+            pin, devb = dec.footprint()
+            peak_pin, peak_dev = max(peak_pin, pin), max(peak_dev, devb)
+            min_free = min(min_free, gpu.cuda.mem_get_info()[0])
+        assert calls < 400000
+    assert pos == len(comp)
+    return crc, got, peak_pin, peak_dev, min_free
+
+
+def test_streaming_memory_stays_bounded_over_a_long_zstd_frame(gpu, alice):
+    """A 192 MiB windowed frame (1 MiB window, content size and checksum in the frame) fed in 64 KiB pieces: the decoder drops
+    input in front of the last block and output behind the window that has been handed on, and carries the XXH64 state from
+    block to block -- O(window + piece), as ZSTD_decompressStream holds it (src/decoder/zstd.rs:98-148)."""
+    import zlib
+
+    import compu_amd as compu
+
+    z = zstd_ref.load()
+    rnd = random.Random(78)
+    total = 192 << 20
+    data = bytearray()
+    while len(data) < total:
+        kind = rnd.randrange(3)
+        if kind == 0:
+            s0 = rnd.randrange(0, len(alice) - 65536)
+            data += (alice[s0 : s0 + 65536]) * 16
+        elif kind == 1:
+            data += rnd.randbytes(1 << 20)
+        else:
+            data += bytes([rnd.randrange(256)]) * (1 << 20)
+    want_crc = zlib.crc32(data)
+    comp = _compress_windowed(z, data, 1, 20)
+    made = len(data)
+    del data
+    dec = compu.decoder_interface.zstd_hip()
+    free0 = gpu.cuda.mem_get_info()[0]
+    crc, got, peak_pin, peak_dev, min_free = _stream_through(compu, dec, comp, 64 << 10, 256 << 10, gpu)
+    assert got == made and crc == want_crc
+    assert peak_pin <= 4 << 20 and peak_dev <= 24 << 20, (peak_pin, peak_dev)
+    assert free0 - min_free <= 64 << 20, (free0, min_free)  # hipMemGetInfo: no growth with the frame's length
+    # a corrupted checksum at the very end is still found (the running state, not a re-read of the output, decides)
+    dec.reset()
+    bad = bytearray(comp)
+    bad[-1] ^= 0x55
+    out = bytearray(1 << 20)
+    pos, status = 0, None
+    while True:
+        chunk = bytes(bad[pos : pos + (1 << 20)])
+        r = dec.decode(chunk, out)
+        if not r.is_ok():
+            status = r.status
+            break
+        pos += len(chunk) - r.input_remain
+        assert r.status != compu.DecodeStatus.Finished
+    assert status == compu.DecodeError(-22)  # ZSTD_error_checksum_wrong
+
+
+def test_streaming_a_zstd_window_larger_than_the_device_buffer(gpu, alice):
+    """A 16 MiB window with matches that reach 12 MiB back (long-distance matching): the device output grows to hold the window
+    (the 8 MiB soft limit gives way when a run makes no progress), the bytes are right, and a frame without a content size works
+    the same."""
+    import zlib
+
+    import compu_amd as compu
+
+    z = zstd_ref.load()
+    rnd = random.Random(79)
+    a = bytearray()
+    while len(a) < (12 << 20):
+        s0 = rnd.randrange(0, len(alice) - 4096)
+        a += alice[s0 : s0 + rnd.randrange(64, 4096)] + rnd.randbytes(rnd.randrange(16, 512))
+    data = bytearray(a) + a[: 6 << 20] + bytearray(rnd.randbytes(1 << 20)) + a[3 << 20 : 9 << 20]
+    want_crc = zlib.crc32(data)
+    for content_size in (True, False):
+        comp = _compress_windowed(z, data, 3, 24, ldm=True, content_size=content_size)
+        assert len(comp) < len(data) * 0.7  # the far copies were found: offsets beyond 8 MiB are in the frame
+        dec = compu.decoder_interface.zstd_hip()
+        crc, got, _, peak_dev, _ = _stream_through(compu, dec, comp, 256 << 10, 1 << 20, gpu, every=8)
+        assert got == len(data) and crc == want_crc
+        assert (16 << 20) <= peak_dev <= (72 << 20), peak_dev
