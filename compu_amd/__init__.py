@@ -18,6 +18,7 @@ from .api import (  # noqa: F401
     Detection,
     Encode,
     EncodeOp,
+    F_COMPU_STATUS,
     EncodeStatus,
     Encoder,
     Vec,

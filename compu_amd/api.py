@@ -91,6 +91,8 @@ def lib():
     L.chip_decoder_strerror.argtypes = [C.c_int, i32]
     L.chip_decode_batch.restype = C.c_int
     L.chip_decode_batch.argtypes = [C.c_int, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.chip_decode_batch_ex.restype = C.c_int
+    L.chip_decode_batch_ex.argtypes = [C.c_int, C.c_uint32, sz, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.chip_detect.restype = C.c_int
     L.chip_detect.argtypes = [vp, sz]
     L.chip_detect_batch.restype = C.c_int
@@ -716,8 +718,11 @@ def _check_tensors(pairs):
     return dev
 
 
-def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len=None, in_used=None, status=None, stream=None):
-    """chip_decode_batch on device tensors: in_buf/out_buf uint8, *_off int64 (read as u64),
+F_COMPU_STATUS = 1  # CHIP_F_COMPU_STATUS
+
+
+def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len=None, in_used=None, status=None, stream=None, flags=0):
+    """chip_decode_batch[_ex] on device tensors: in_buf/out_buf uint8, *_off int64 (read as u64),
     in_len/out_cap/out_len/in_used int32 (read as u32), status int32.  Only enqueues."""
     import torch
 
@@ -732,8 +737,8 @@ def decode_batch(fmt, in_buf, in_off, in_len, out_buf, out_off, out_cap, out_len
     _check_tensors(((in_buf, torch.uint8), (out_buf, torch.uint8), (in_off, torch.int64), (out_off, torch.int64), (in_len, torch.int32),
                     (out_cap, torch.int32), (out_len, torch.int32), (in_used, torch.int32), (status, torch.int32)))
     with torch.cuda.device(dev):  # scratch and the stream come from the tensors' device, not whatever is current
-        rc = lib().chip_decode_batch(int(fmt), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off), _dp(out_cap),
-                                     _dp(out_len), _dp(in_used), _dp(status), _stream_ptr(stream))
+        rc = lib().chip_decode_batch_ex(int(fmt), int(flags), n, _dp(in_buf), _dp(in_off), _dp(in_len), _dp(out_buf), _dp(out_off), _dp(out_cap),
+                                        _dp(out_len), _dp(in_used), _dp(status), _stream_ptr(stream))
     if rc != 0:
         raise RuntimeError(f"chip_decode_batch failed: {rc}")
     return out_len, in_used, status

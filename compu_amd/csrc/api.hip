@@ -127,6 +127,14 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
                       void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
                       uint32_t *in_used, int32_t *status, void *stream)
 {
+    return chip_decode_batch_ex(format, 0, n, in_base, in_off, in_len, out_base, out_off, out_cap, out_len, in_used, status, stream);
+}
+
+int chip_decode_batch_ex(int format, uint32_t flags, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                         void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                         uint32_t *in_used, int32_t *status, void *stream)
+{
+    if (flags & ~(uint32_t)CHIP_F_COMPU_STATUS) return CHIP_E_INVALID;
     if (n == 0) return CHIP_OK;
     if (n > 0x7fffffffull || !in_base || !in_off || !in_len || !out_base || !out_off || !out_cap || !out_len || !in_used ||
         !status || ((uintptr_t)in_base & 3u))
@@ -148,6 +156,7 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
     a.resume = nullptr;
     a.sel = nullptr;
     a.sel_n = nullptr;
+    a.flags = flags;
 #ifdef CHIP_STATS
     a.stats = (unsigned long long *)getenv("CHIP_STATS_PTR") ? (unsigned long long *)strtoull(getenv("CHIP_STATS_PTR"), nullptr, 0) : nullptr;
 #endif

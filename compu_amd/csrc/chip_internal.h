@@ -60,7 +60,9 @@ struct BatchArgs {
     // pointers, written by route_kernel earlier on the same stream); nullptr = all n units in index order.
     const uint32_t *sel = nullptr;
     const uint32_t *sel_n = nullptr;
+    uint32_t flags = 0;  // CHIP_F_* of chip_decode_batch_ex (include/compu_hip.h)
 };
+constexpr uint32_t F_COMPU_STATUS = 1u;  // = CHIP_F_COMPU_STATUS
 
 // launchers (each only enqueues on `stream`)
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);

@@ -741,10 +741,73 @@ __device__ __forceinline__ void round_finish(const Round &r, const ChunkLds &C, 
     }
 }
 
+// lane i's value of x from lane `src` (any lane; ds_bpermute: no LDS memory is touched)
+__device__ __forceinline__ uint32_t lane_gather(uint32_t x, uint32_t src)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
+}
+
+// ---- CHIP_F_COMPU_STATUS only (rare path): where zlib's inflate() stands when the output has filled ---------------
+// zlib leaves with every bit of the token consumed during which (or, when the output was exactly full, in front of which) it ran
+// out of room, and holds fewer than eight unused bits: its avail_in follows from the bit position behind that token.
+// End of the token that starts at bit p (never an end-of-block code), read from memory with the block's tables.
+__device__ uint32_t token_end(const WaveLds &L, const InWin &w, uint32_t p)
+{
+    const uint16_t *const pool16 = (const uint16_t *)L.pool;
+    const uint32_t i = p >> 5;
+    const uint32_t d0 = i < w.total_dw ? w.g32[i] : 0u, d1 = i + 1u < w.total_dw ? w.g32[i + 1u] : 0u, d2 = i + 2u < w.total_dw ? w.g32[i + 2u] : 0u;
+    const uint32_t lo = __builtin_amdgcn_alignbit(d1, d0, p), hi = __builtin_amdgcn_alignbit(d2, d1, p);
+    const uint32_t r = L.lit_root[lo & ((1u << LIT_ROOT) - 1u)];
+    const uint32_t e = L.pool[(r >> 5) + __builtin_amdgcn_ubfe(lo, LIT_ROOT, r)];
+    const uint32_t n1 = __builtin_amdgcn_ubfe(e, 10, 5);
+    if (!(e & F_LEN)) return p + n1;
+    const uint32_t w2 = __builtin_amdgcn_alignbit(hi, lo, n1);
+    uint32_t m = L.dist_root[w2 & ((1u << DIST_ROOT) - 1u)];
+    if (m & D_LONG) {
+        const uint32_t b16 = ((m >> 4) & 127u) | ((m >> 12) << 7);
+        m = pool16[b16 + __builtin_amdgcn_ubfe(w2, DIST_ROOT, m)];
+    }
+    return p + n1 + (m & 15u) + __builtin_amdgcn_ubfe(m, 4, 4);
+}
+
+// The chunk that began with stream token `cstart` at image offset `run0` overflowed the room `xcap` (image offsets): bit position
+// behind the first token that does not fit entirely.  B = the super-round's first bit (lane l's chain starts at B + l * S_BITS).
+__device__ __attribute__((always_inline)) uint32_t overflow_bit(const WaveLds &L, const InWin &w, const uint32_t *grow, uint32_t ntok, uint32_t npieces,
+                                                           uint32_t cstart, uint32_t run0, uint32_t xcap, uint32_t B)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t pfirst = lane < npieces ? L.fl.pk[2u * lane] : 0xffffffffu;
+    const uint32_t pdelta = lane < npieces ? L.fl.pk[2u * lane + 1u] : 0u;
+    uint32_t run = run0;
+    for (uint32_t g = cstart; g < ntok; g += 64u) {
+        const uint32_t t = g + lane < ntok ? g + lane : ntok - 1u;
+        uint32_t k = 0;  // pieces that start at or before token t
+        for (uint32_t q = 0; q < npieces; q++) k += rdlane(pfirst, q) <= t ? 1u : 0u;
+        const uint32_t d = lane_gather(pdelta, k - 1u);
+        const uint32_t krow = (t + d) & 0xffffu, rb = d >> 16;
+        const uint32_t tok = grow[rb + row_word(krow)];
+        uint32_t olen = (tok & 512u) ? (tok & 0x1ffu) : 1u;
+        if (g + lane >= ntok) olen = 0;
+        const uint32_t incl = wave_incl_scan(olen);
+        const uint64_t over = __ballot(olen != 0 && run + incl > xcap);
+        if (over) {
+            const uint32_t f = (uint32_t)__ffsll((long long)over) - 1u;
+            const uint32_t rbf = rdlane(rb, f), kf = rdlane(krow, f);
+            const uint32_t owner = ((rbf / (8u * ROW_TOKENS)) << 3) | ((rbf % (8u * ROW_TOKENS)) >> 2);  // row_base() inverted
+            uint32_t p = B + owner * S_BITS;
+            for (uint32_t j = 0; j <= kf; j++) p = rdfirst(token_end(L, w, p));
+            return p;
+        }
+        run += rdlane(incl, 63u);
+    }
+    return 0;  // (not reached: the caller saw the overflow)
+}
+
 // Executes the ntok tokens of a batch of the true stream (npieces pieces described by L.fl.pk) into gout at opos.
 // Returns false when decoding must stop (error / output full).
+// (ovf: on CHIP_NEED_OUTPUT the overflowing chunk's first stream token, first image offset and room, for overflow_bit())
 __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, uint32_t ntok_, uint32_t npieces_, uint8_t *gout_, uint32_t &opos_,
-                             uint32_t cap_, int32_t &status STAT_PARAM)
+                             uint32_t cap_, int32_t &status, uint32_t (&ovf)[3] STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     // every argument is wave-uniform; say so (scalar registers, scalar loop branches)
@@ -805,7 +868,7 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
     for (uint32_t k = 0; k < TOK_RING; k++) fetch();
     // ---- chunk state (every piece of code below exists once: no closures, everything stays in registers)
     bool fresh = true;  // a chunk starts with the next group
-    uint32_t mis = 0, run = 0, nq = 0, qh = 0, prod0 = 0;
+    uint32_t mis = 0, run = 0, nq = 0, qh = 0, prod0 = 0, cstart = 0;
     uint8_t *base = gout;
     bool glob_ok = false, inflight = false;
     Round R;
@@ -818,6 +881,7 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
             run = mis;
             prod0 = opos - mis;  // output bytes in front of offset 0
             nq = qh = 0;
+            cstart = c0;
             fresh = false;
         }
         static_assert(TOK_RING == 4, "the wait below counts three younger ring loads");
@@ -914,8 +978,8 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         }
         if (!ending) continue;
         // ---- the finished chunk: offsets [mis, min(run, capacity)) of the LDS image go to HBM
+        const uint32_t xcap = cap - (opos - mis);
         {
-            const uint32_t xcap = cap - (opos - mis);
             const uint32_t xe = run < xcap ? run : xcap;
             for (uint32_t xq = 4u * lane; xq < xe; xq += 256u) {
                 const uint32_t wv = C.out[xq >> 2];
@@ -935,6 +999,9 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         if (opos > cap) {
             opos_ = cap;
             status = CHIP_NEED_OUTPUT;
+            ovf[0] = cstart;
+            ovf[1] = mis;
+            ovf[2] = xcap;
             return false;
         }
         if (too_far) {
@@ -948,11 +1015,6 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
 // ---- the walk of a super-round -----------------------------------------------------------------------------
 constexpr size_t SCRATCH_WORDS = ROWS_WORDS;
 
-// lane i's value of x from lane `src` (any lane; ds_bpermute: no LDS memory is touched)
-__device__ __forceinline__ uint32_t lane_gather(uint32_t x, uint32_t src)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x);
-}
 
 // why a lane's chain ended
 enum : uint32_t { R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 5 };
@@ -1130,7 +1192,8 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
 // Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them into gout.  On return `pos` is
 // behind the end-of-block code (status stays ST_RUNNING) or status holds the reason decoding stopped.
 __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
-                                           const uint32_t cap, int32_t &status, uint32_t *rows, const uint32_t xt_bits, const uint32_t eob_len STAT_PARAM)
+                                           const uint32_t cap, int32_t &status, uint32_t *rows, const uint32_t xt_bits, const uint32_t eob_len,
+                                           const uint32_t flags STAT_PARAM)
 {
     pos = rdfirst(pos);
     opos = rdfirst(opos);
@@ -1144,11 +1207,14 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         const uint32_t npk = walk_round(L, w, pos, end_bit, rows, xt_bits, ntok, why, tpos STAT_ARG);
         int32_t st2 = ST_RUNNING;
         bool flushed = true;
-        if (npk) flushed = flush_tokens(L, rows, ntok, npk, gout, opos, cap, st2 STAT_ARG);
+        uint32_t ovf[3] = {0, 0, 0};
+        if (npk) flushed = flush_tokens(L, rows, ntok, npk, gout, opos, cap, st2, ovf STAT_ARG);
         w.win0 = 0xffffffffu;  // the phases used the header window's place
         STAT_ACC(20);
         if (!flushed) {
             status = st2;
+            // CHIP_F_COMPU_STATUS: zlib's position when the output filled (else the position stays at the round's start)
+            if ((flags & F_COMPU_STATUS) && st2 == CHIP_NEED_OUTPUT) pos = overflow_bit(L, w, rows, ntok, npk, ovf[0], ovf[1], ovf[2], pos);
             return;
         }
         if (why == R_NEED_INPUT) {
@@ -1391,7 +1457,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
         }
         STAT_ACC(0);
         __builtin_amdgcn_s_setprio(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len STAT_ARG);
+        decode_block(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len, a.flags STAT_ARG);
         __builtin_amdgcn_s_setprio(2);  // block headers and table builds are short dependent chains: ahead of the other waves' bulk work
         STAT_T0();
     }
@@ -1448,9 +1514,15 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
             rs[5] = out_dropped;
         }
     }
+    uint32_t used = (pos - start_bit + 7u) >> 3;
+    if (used > in_len) used = in_len;
+    if (a.flags & F_COMPU_STATUS) {
+        // compu's reading of zlib's return code, src/decoder/mod.rs:475-483: Z_OK with avail_in == 0 is NeedInput whatever
+        // else ran out, and a call that could not move (no input at all: Z_BUF_ERROR) is NeedOutput
+        if (status == CHIP_NEED_OUTPUT && used == in_len) status = CHIP_NEED_INPUT;
+        else if (status == CHIP_NEED_INPUT && in_len == 0) status = CHIP_NEED_OUTPUT;
+    }
     if (lane == 0) {
-        uint32_t used = (pos - start_bit + 7u) >> 3;
-        if (used > in_len) used = in_len;
         a.out_len[u] = opos;
         a.in_used[u] = status == CHIP_NEED_INPUT ? in_len : used;
         a.status[u] = status;

@@ -873,7 +873,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
 
     int32_t status = ST_RUNNING;
     uint32_t ip = B0;  // absolute byte cursor
-    uint32_t opos = 0;
+    uint32_t opos = 0, blk0 = 0;  // output cursor; where the block being decoded starts
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool has_checksum = false, has_fcs = false;
     uint64_t fcs = 0, window = 0, out_limit = ~0ULL;
@@ -1005,6 +1005,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
 
     // ---- blocks (sec. 3.1.1.2) --------------------------------------------------------------------
     while (!blocks_done) {
+        blk0 = opos;
         if (END - ip < 3) ZNEED_INPUT();
         const uint32_t bh = rd32_at(b, ip * 8u) & 0xffffffu;
         const uint32_t last = bh & 1u, type = (bh >> 1) & 3u, bsz = bh >> 3;
@@ -1701,6 +1702,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         }
         save_checkpoint(blocks_done);
     }
+    blk0 = opos;
     if (has_checksum) {
         if (END - ip < 4) ZNEED_INPUT();
         uint32_t want = rd32_at(b, ip * 8u);
@@ -1720,6 +1722,15 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
     }
     status = CHIP_FINISHED;
 done:
+    if ((a.flags & F_COMPU_STATUS) && status != CHIP_FINISHED) {
+        // compu looks at the output first: whatever ZSTD_decompressStream returned, an output buffer that is full means
+        // NeedOutput (src/decoder/zstd.rs:121-133).  libzstd hands on whole blocks in front of an error.
+        const uint32_t ready = status < 0 ? blk0 : opos;
+        if (ready >= cap) {
+            status = CHIP_NEED_OUTPUT;
+            opos = cap;
+        }
+    }
     if (rs && lane == 0 && status != CHIP_NEED_INPUT && status != CHIP_NEED_OUTPUT) rs[0] = 0;  // nothing to continue
     if (lane == 0) {
         a.out_len[u] = opos;

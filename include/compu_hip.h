@@ -157,6 +157,21 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
                       uint32_t *in_used, int32_t *status, void *stream);
 
 /*
+ * The same with options.  CHIP_F_COMPU_STATUS: status[i] is what compu's decode_fn would have returned for the unit, to the
+ * letter, where the default names the cause instead --
+ *   deflate / zlib / gzip (src/decoder/mod.rs:475-483): zlib's Z_OK with avail_in == 0 is NeedInput even when it was the
+ *     output that filled (in_used[i] is then zlib's count: every bit of the token during which the room ran out, rounded up
+ *     to a byte), and a unit without any input is NeedOutput (zlib's Z_BUF_ERROR);
+ *   zstd (src/decoder/zstd.rs:121-133): an output range that is full is NeedOutput whatever else ZSTD_decompressStream said --
+ *     an error behind whole blocks that fill out_cap[i] exactly, a truncated frame whose bytes so far fill it.
+ * Everything else is identical.  Unknown flag bits: CHIP_E_INVALID.
+ */
+enum { CHIP_F_COMPU_STATUS = 1 };
+int chip_decode_batch_ex(int format, uint32_t flags, size_t n, const void *in_base, const uint64_t *in_off, const uint32_t *in_len,
+                         void *out_base, const uint64_t *out_off, const uint32_t *out_cap, uint32_t *out_len,
+                         uint32_t *in_used, int32_t *status, void *stream);
+
+/*
  * The same for data that starts and ends in HOST memory (SURVEY.md sec. 8b "pinned-host variant", 8e): every
  * pointer is a host pointer (hipHostMalloc / chip_pinned_alloc memory lets the copies run asynchronously; pageable
  * memory works but serialises them).  The units are cut into slices (about `slice_bytes` of input + output each,

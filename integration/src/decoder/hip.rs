@@ -225,7 +225,10 @@ pub fn decode_batch_multi(format: BatchFormat, devices: &[i32], input: &[u8], un
 ///
 ///The offset / length arrays are read by the GPU: they must describe ranges inside `input` and `output`, and all buffers must
 ///stay alive until the stream has been synchronised.
-pub unsafe fn decode_batch_device(format: BatchFormat, n: usize, input: &crate::buffer::DeviceBuffer, in_off: &crate::buffer::DeviceBuffer,
+///
+///`compu_status`: report every unit's status exactly as this crate's `decode_fn` would have (`CHIP_F_COMPU_STATUS`); `false` names the
+///limit that was hit (see `include/compu_hip.h`).
+pub unsafe fn decode_batch_device(format: BatchFormat, compu_status: bool, n: usize, input: &crate::buffer::DeviceBuffer, in_off: &crate::buffer::DeviceBuffer,
                                   in_len: &crate::buffer::DeviceBuffer, output: &mut crate::buffer::DeviceBuffer, out_off: &crate::buffer::DeviceBuffer,
                                   out_cap: &crate::buffer::DeviceBuffer, out_len: &mut crate::buffer::DeviceBuffer, in_used: &mut crate::buffer::DeviceBuffer,
                                   status: &mut crate::buffer::DeviceBuffer, stream: *mut core::ffi::c_void) -> Result<(), i32> {
@@ -234,9 +237,10 @@ pub unsafe fn decode_batch_device(format: BatchFormat, n: usize, input: &crate::
     {
         return Err(-101);
     }
-    let rc = sys::chip_decode_batch(format.tag(), n, input.as_ptr() as *const _, in_off.as_ptr() as *const u64, in_len.as_ptr() as *const u32,
-                                    output.as_mut_ptr() as *mut _, out_off.as_ptr() as *const u64, out_cap.as_ptr() as *const u32,
-                                    out_len.as_mut_ptr() as *mut u32, in_used.as_mut_ptr() as *mut u32, status.as_mut_ptr() as *mut i32, stream);
+    let flags = if compu_status { sys::CHIP_F_COMPU_STATUS } else { 0 };
+    let rc = sys::chip_decode_batch_ex(format.tag(), flags, n, input.as_ptr() as *const _, in_off.as_ptr() as *const u64, in_len.as_ptr() as *const u32,
+                                       output.as_mut_ptr() as *mut _, out_off.as_ptr() as *const u64, out_cap.as_ptr() as *const u32,
+                                       out_len.as_mut_ptr() as *mut u32, in_used.as_mut_ptr() as *mut u32, status.as_mut_ptr() as *mut i32, stream);
     if rc == sys::CHIP_OK { Ok(()) } else { Err(rc) }
 }
 

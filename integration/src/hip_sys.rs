@@ -47,6 +47,8 @@ pub const CHIP_FMT_ZSTD: c_int = 100;
 ///route every unit of a batch by `Detection::detect` (src/decoder/mod.rs:28-114)
 pub const CHIP_FMT_DETECT: c_int = 0;
 
+///`chip_decode_batch_ex` flag: report `DecodeStatus` exactly as compu's `decode_fn` would
+pub const CHIP_F_COMPU_STATUS: u32 = 1;
 ///`chip_decode_batch` / `chip_encode_batch` return codes
 pub const CHIP_OK: c_int = 0;
 
@@ -79,6 +81,10 @@ extern "C" {
     // ---- the batched hot path (additive API): n independent units per launch, one wavefront per unit
     pub fn chip_decode_batch(format: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, out_base: *mut c_void,
                              out_off: *const u64, out_cap: *const u32, out_len: *mut u32, in_used: *mut u32, status: *mut i32, stream: *mut c_void) -> c_int;
+    ///`flags`: `CHIP_F_COMPU_STATUS` makes `status[i]` compu's own reading of the codec's return code (`src/decoder/mod.rs:475-483`,
+    ///`src/decoder/zstd.rs:121-133`) where the default names the cause
+    pub fn chip_decode_batch_ex(format: c_int, flags: u32, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, out_base: *mut c_void,
+                                out_off: *const u64, out_cap: *const u32, out_len: *mut u32, in_used: *mut u32, status: *mut i32, stream: *mut c_void) -> c_int;
     pub fn chip_decode_batch_host(format: c_int, n: usize, in_base: *const c_void, in_off: *const u64, in_len: *const u32, out_base: *mut c_void,
                                   out_off: *const u64, out_cap: *const u32, out_len: *mut u32, in_used: *mut u32, status: *mut i32, device: c_int,
                                   slice_bytes: usize) -> c_int;

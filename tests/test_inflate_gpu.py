@@ -22,7 +22,7 @@ def _pack(parts):
     return buf, offs, lens
 
 
-def run_batch(torch, fmt, parts, caps, check_tail=True):
+def run_batch(torch, fmt, parts, caps, check_tail=True, flags=0):
     """Decode `parts` in one launch; returns (list of outputs, out_len, in_used, status) on the host."""
     import compu_amd
 
@@ -37,7 +37,7 @@ def run_batch(torch, fmt, parts, caps, check_tail=True):
     d_out = torch.full((total_out,), 0xA5, dtype=torch.uint8, device=dev)
     out_len, in_used, status = compu_amd.decode_batch(
         fmt, d_in, torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev), d_out,
-        torch.from_numpy(ooff).to(dev), torch.from_numpy(caps).to(dev))
+        torch.from_numpy(ooff).to(dev), torch.from_numpy(caps).to(dev), flags=flags)
     torch.cuda.synchronize()
     h_out = d_out.cpu().numpy()
     ol, iu, st = out_len.cpu().numpy(), in_used.cpu().numpy(), status.cpu().numpy()
@@ -250,6 +250,51 @@ def test_truncated_corrupt_and_small_caps_match_oracle(gpu, alice):
         assert st[i] == r_st, (i, st[i], r_st)
         if r_st == 2:
             assert iu[i] == r_used, (i, iu[i], r_used)
+
+
+def test_compu_status_flag_reports_the_reference_mapping_verbatim(gpu, alice):
+    """CHIP_F_COMPU_STATUS: the two pinned deviations above disappear -- status AND in_used are the oracle's (= zlib's
+    avail_in at the moment the output filled, src/decoder/mod.rs:475-483) for every unit, whatever ran out."""
+    import compu_amd
+
+    rnd = random.Random(6)
+    parts, caps = [], []
+    for it in range(700):
+        n = rnd.choice([50, 500, 5000, 30000, 120000])
+        data = _mk(rnd.choice([1, 2, 4]), n, rnd, alice)
+        co = zlib.compressobj(rnd.choice([0, 1, 6, 9]), zlib.DEFLATED, -15, 8, rnd.choice([0, 4]))
+        comp = bytearray(co.compress(data) + co.flush())
+        mode = rnd.randrange(5)
+        if mode == 0:
+            comp[rnd.randrange(len(comp))] ^= 1 << rnd.randrange(8)
+        elif mode == 1:
+            comp = comp[: rnd.randrange(len(comp))]
+        cap = n if mode < 2 else rnd.randrange(0, n)  # modes 2..4: the output is too small
+        if mode == 4:  # ... and the input ends close behind the token that does not fit
+            ref = oracle_batch(-15, [bytes(comp)], [cap])[0]
+            comp = comp[: ref[1] + rnd.choice([0, 0, 0, 1, 2])]
+        parts.append(bytes(comp))
+        caps.append(cap)
+    parts += [b"", b""]
+    caps += [0, 100]
+    outs, ol, iu, st = run_batch(gpu, -15, parts, caps, flags=compu_amd.F_COMPU_STATUS)
+    ref = oracle_batch(-15, parts, caps)
+    flipped = 0
+    for i in range(len(parts)):
+        r_out, r_used, r_st = ref[i]
+        assert outs[i] == r_out, (i, len(outs[i]), len(r_out))
+        assert st[i] == r_st, (i, st[i], r_st, caps[i], len(parts[i]))
+        if r_st in (1, 2) and len(parts[i]):
+            assert iu[i] == r_used, (i, iu[i], r_used, r_st)
+        flipped += r_st == 0 and len(r_out) == caps[i] and r_used == len(parts[i]) and len(parts[i]) > 0
+    assert flipped >= 20  # the case the flag exists for was exercised
+    # the flag changes nothing else: wrapped formats, finished units
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    whole = co.compress(alice[:70000]) + co.flush()
+    gz = [whole, whole[:-3], b""]
+    outs, ol, iu, st = run_batch(gpu, 31, gz, [70000, 70000, 10], flags=compu_amd.F_COMPU_STATUS)
+    ref = oracle_batch(31, gz, [70000, 70000, 10])
+    assert [int(x) for x in st] == [r[2] for r in ref] == [2, 0, 1]
 
 
 def test_large_multiblock_streams(gpu, alice):

@@ -121,6 +121,35 @@ def test_truncated_and_corrupt_frames_match_oracle(gpu, alice):
             assert iu[i] == r_used
 
 
+def test_compu_status_flag_puts_a_full_output_first(gpu, alice):
+    """CHIP_F_COMPU_STATUS for zstd (src/decoder/zstd.rs:121-133): a full output range is NeedOutput whatever else happened -- a
+    checksum error behind an exactly sized buffer, a truncated frame whose blocks so far fill it, no room at all."""
+    import compu_amd
+
+    z = zstd_ref.load()
+    data = alice[:100000]
+    good = zstd_ref.compress(z, data, 3, True, True)
+    bad_ck = bytearray(good)
+    bad_ck[-1] ^= 1
+    two = zstd_ref.compress(z, (alice * 3)[:400000], 3, True, False)  # four blocks
+    parts = [bytes(bad_ck), bytes(bad_ck), good, good[:-2], b"\x00\x00\x00\x00", good[:40]]
+    caps = [100000, 100001, 100000, 100000, 0, 0]
+    outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, parts, caps, check_tail=False, flags=compu_amd.F_COMPU_STATUS)
+    ref = oracle_zstd_batch(parts, caps)
+    assert [int(x) for x in st] == [r[2] for r in ref] == [1, -22, 2, 1, 1, 1]
+    outs0, _, _, st0 = run_batch(gpu, FMT_ZSTD, parts, caps, check_tail=False)
+    assert [int(x) for x in st0] == [-22, -22, 2, 0, -10, 0]  # the default names the cause
+    # a truncated multi-block frame: the whole blocks in front of the cut fill the buffer exactly
+    full, _, _, s_full = run_batch(gpu, FMT_ZSTD, [two], [400000], check_tail=False)
+    assert s_full[0] == 2
+    cut = two[: len(two) * 9 // 10]
+    o, l, _, s = run_batch(gpu, FMT_ZSTD, [cut], [400000], check_tail=False)
+    assert s[0] == 0 and 0 < l[0] < 400000
+    o2, l2, _, s2 = run_batch(gpu, FMT_ZSTD, [cut, cut], [int(l[0]), int(l[0]) + 1], check_tail=False, flags=compu_amd.F_COMPU_STATUS)
+    r2 = oracle_zstd_batch([cut, cut], [int(l[0]), int(l[0]) + 1])
+    assert [int(x) for x in s2] == [r[2] for r in r2] == [1, 0] and o2[0] == o2[1] == o[0]
+
+
 def test_mixed_gzip_zstd_batch_routed_by_detection(gpu, alice):
     """BASELINE.json configs[4] in small: a batch of gzip, zlib and zstd units routed per unit by
     Detection::detect (src/decoder/mod.rs:28-114); unknown units are reported, not decoded."""
