@@ -9,7 +9,7 @@
 //
 // Per 64-position chunk: every lane hashes the 4 bytes at its position, looks the hash table (LDS,
 // state before the chunk) up, measures the common prefix with the candidate (16-byte compares from
-// HBM/L2), the table then takes the highest position per slot (ds_max), the greedy token choice is
+// HBM/L2), the table then takes the highest position per slot (16-bit entries), the greedy token choice is
 // a scalar walk over the chosen matches.  Level 1: the tokens are packed at once with a wave prefix sum
 // of their bit lengths into an LDS bit buffer that is flushed to HBM.  Levels 2..9: the tokens go to HBM
 // scratch and are coded when the block closes (code lengths, header, second pass over the tokens).
@@ -25,15 +25,15 @@ namespace {
 
 constexpr int HASH_BITS = 12;
 constexpr uint32_t MIN_MATCH = 4, MAX_MATCH = 258, MAX_DIST = 32768;
-constexpr int OUT_DW = 448;  // LDS bit buffer, dwords (a chunk adds at most 62)
+constexpr int OUT_DW = 192;  // LDS bit buffer, dwords (a chunk adds at most 62); with the table and lentab: 10 240 B = sixteen waves per CU
 
 struct alignas(16) ELds {
     static constexpr uint32_t OBUF = OUT_DW + 64;
-    uint32_t table[1 << HASH_BITS];
+    uint16_t table[1 << HASH_BITS];  // low 16 bits of the highest position with that hash (oracle_deflate.c states the rule)
     uint32_t obuf[OBUF];
     uint32_t lentab[256];  // per match length 3..258: fixed-Huffman code with the extra bits | bit count << 16
 };
-static_assert(sizeof(ELds) <= 20480, "eight waves per CU");
+static_assert(sizeof(ELds) <= 10240, "sixteen waves per CU (LDS is granted in 1280-byte steps)");
 
 // 4 input bytes at byte offset `off` of the dword-aligned view (little endian)
 __device__ __forceinline__ uint32_t ld32(const uint32_t *g32, uint32_t total_dw, uint32_t off)
@@ -168,7 +168,7 @@ __device__ __constant__ static const uint8_t CL_ORDER[20] = {16, 17, 18, 0, 8, 7
 
 struct alignas(16) DLds {
     static constexpr uint32_t OBUF = 416;  // dwords; a group of 64 tokens adds at most 96
-    uint32_t table[1 << HASH_BITS];
+    uint16_t table[1 << HASH_BITS];
     uint32_t obuf[OBUF];
     uint32_t lfreq[288], dfreq[32], cfreq[20];
     union {
@@ -186,7 +186,7 @@ struct alignas(16) DLds {
     uint8_t ll[288], dl[32], cl[20];
     uint32_t lentab[256];  // per match length 3..258: length code 0..28 | extra-bit count << 8 | extra-bit value << 16
 };
-static_assert(sizeof(DLds) <= 26624, "six waves per CU (LDS is granted in 1 KB steps: 27 KB would leave five)");
+static_assert(sizeof(DLds) <= 19200, "eight waves per CU (LDS is granted in 1280-byte steps)");
 
 // Code lengths of freq[0..n) (n <= 288) limited to maxbits into len[0..n): Huffman over (frequency, symbol)-sorted
 // leaves, two-queue merge with ties to the leaf; too deep -> all frequencies halved (rounding up) and rebuilt.
@@ -402,7 +402,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
     const uint32_t *g32 = (const uint32_t *)(gin - mis);
     const uint32_t total_dw = (mis + n + 3u) >> 2;
 
-    for (uint32_t j = lane; j < (1u << HASH_BITS); j += 64) L.table[j] = 0;
+    for (uint32_t j = lane; j < (1u << HASH_BITS) / 2; j += 64) ((uint32_t *)L.table)[j] = 0;
     for (uint32_t j = lane; j < LDS::OBUF; j += 64) L.obuf[j] = 0;
     for (uint32_t j = lane; j < 256; j += 64) {
         uint32_t lc, lext, lxv;
@@ -480,10 +480,10 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             c.q = p;
             if (valid4) {
                 h = (c.v * 2654435761u) >> (32 - HASH_BITS);
-                const uint32_t t = L.table[h];
-                if (t && p - (t - 1) <= MAX_DIST) {
+                const uint32_t dist = (p - L.table[h]) & 0xffffu;  // the nearest earlier position with the slot's low 16 bits
+                if (dist - 1u < MAX_DIST && dist <= p) {
                     c.has = true;
-                    c.q = t - 1;
+                    c.q = p - dist;
                 }
                 // Z_RLE: the only candidate is the byte before (distance 1); Z_HUFFMAN_ONLY: none
                 if (rle) {
@@ -501,7 +501,15 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             c.qv = *(const U128u *)(gwide + (c.q < wide_end ? c.q : wide_end));
             c.pv = *(const U128u *)(gwide + (p < wide_end ? p : wide_end));
             LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the loads stay in flight)
-            if (valid4) atomicMax(&L.table[h], p + 1);
+            // The highest position of a slot stands.  (LDS has no 16-bit maximum: all write, a lane that finds a lower lane of
+            // this chunk in its slot writes again -- a second round in one chunk of five, hardly ever a third.)
+            if (valid4) L.table[h] = (uint16_t)p;
+            for (;;) {
+                LSYNC();
+                const bool lost = valid4 && ((L.table[h] - base) & 0xffffu) < lane;
+                if (!__any(lost)) break;
+                if (lost) L.table[h] = (uint16_t)p;
+            }
         };
         // one chunk: look the next one up (its loads fly while this one is worked on), measure, choose, emit
         auto step = [&](Cand &cur, Cand &nxt, const uint32_t base) __attribute__((always_inline)) {

@@ -13,7 +13,11 @@
  * Algorithm (level >= 1): greedy parse over 64-position chunks.  Every position of a chunk looks up
  * a 4096-entry hash table of 4-byte hashes as it stood BEFORE the chunk (so candidates are at least
  * one chunk back and the 64 lookups are independent), the match length is the common prefix (4..258
- * bytes, distance <= 32768), then the table takes the highest position per slot.  Tokens are chosen
+ * bytes, distance <= 32768), then the table takes the highest position per slot.  A slot holds the low
+ * 16 bits of a position: the candidate is the nearest earlier position with those low bits (distance
+ * (p - slot) mod 65536, none if that is 0, more than 32768 or more than p) -- a slot that was never
+ * written (0) or not for 64 KiB names some other position, and like every candidate it only counts
+ * if four bytes there match.  Tokens are chosen
  * greedily left to right.  Level 1 (and Z_FIXED): emitted with the fixed Huffman code (RFC 1951
  * sec. 3.2.6); a segment whose fixed-Huffman form is not smaller than stored blocks is emitted stored.
  * Levels 2..9: dynamic-Huffman blocks (write_block below); from level 4 on the choice is lazy: a match
@@ -91,7 +95,7 @@ static size_t stored_size(size_t n, int sync)
 }
 
 /* ---- the match finder: one 64-position chunk -> tokens ---------------------------------------- */
-typedef struct { uint32_t table[1u << HASH_BITS]; size_t skip; } matcher;
+typedef struct { uint16_t table[1u << HASH_BITS]; size_t skip; } matcher;
 
 #define TOK_MATCH 0x80000000u
 #define TOK_LEN(t) (((t) & 0xffu) + 3u)
@@ -103,7 +107,7 @@ static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t bas
 {
     unsigned mlen[64], mdist[64], nt = 0;
     uint32_t hh[64];
-    uint32_t *table = m->table;
+    uint16_t *table = m->table;
     for (unsigned l = 0; l < 64; l++) {
         size_t p = base + l;
         mlen[l] = 0;
@@ -113,18 +117,19 @@ static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t bas
         uint32_t v = (uint32_t)in[p] | ((uint32_t)in[p + 1] << 8) | ((uint32_t)in[p + 2] << 16) | ((uint32_t)in[p + 3] << 24);
         uint32_t h = (v * 2654435761u) >> (32 - HASH_BITS);
         hh[l] = h;
-        uint32_t c = table[h];
+        uint32_t dist = ((uint32_t)p - table[h]) & 0xffffu;
+        if (dist > MAX_DIST || dist > p) dist = 0;
         /* strategy 3 (Z_RLE): the only candidate is the byte before; 2 (Z_HUFFMAN_ONLY): none */
-        if (strategy == 3) c = p > 0 ? (uint32_t)p : 0;
-        if (strategy == 2) c = 0;
-        if (c && p - (c - 1) <= MAX_DIST) {
-            size_t q = c - 1, lim = n - p < MAX_MATCH ? n - p : MAX_MATCH, k = 0;
+        if (strategy == 3) dist = p > 0 ? 1 : 0;
+        if (strategy == 2) dist = 0;
+        if (dist) {
+            size_t q = p - dist, lim = n - p < MAX_MATCH ? n - p : MAX_MATCH, k = 0;
             while (k < lim && in[q + k] == in[p + k]) k++;
             if (k >= MIN_MATCH) { mlen[l] = (unsigned)k; mdist[l] = (unsigned)(p - q); }
         }
     }
     for (unsigned l = 0; l < 64; l++)
-        if (hh[l] != 0xffffffffu && table[hh[l]] < base + l + 1) table[hh[l]] = (uint32_t)(base + l + 1);
+        if (hh[l] != 0xffffffffu) table[hh[l]] = (uint16_t)(base + l); /* ascending: the highest position stands */
     size_t pos = m->skip;
     while (pos < 64 && base + pos < n) {
         /* lazy (levels 4..9, like zlib from level 4 on): a match gives way to a longer one at the next position of the chunk */
