@@ -1259,16 +1259,17 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     } else if (!*t.valid) ZFAIL(ZSTD_E_CORRUPTION);
                     if (mode != 3) {
                         // A freshly built table is re-coded for the serial state chain below: [4:0] state bits (used as
-                        // they are as v_bfe widths and offsets), [11:5] state bits + extra bits of the code (the sum of
-                        // the three entries' low halves gives the bits a sequence consumes), [17:12] the code,
-                        // [31:23] the baseline of the next state.
+                        // they are as v_bfe widths and offsets), [11:5] MINUS (state bits + extra bits of the code) modulo 128
+                        // (the sum of the three entries gives minus the bits a sequence consumes: as a signed field it moves
+                        // the bit position, and its low six bits are 64 - bits, the shift that brings the state bits of
+                        // the 64-bit view to the bottom), [17:12] the code, [31:23] the baseline of the next state.
                         WSYNC();
                         const uint32_t *xt = k == 0 ? L.lltab : L.mltab;
                         const uint32_t size = 1u << *t.al;
                         for (uint32_t u = lane; u < size; u += 64) {
                             const uint32_t e = t.e[u], sym = e & 63u, nb = (e >> 6) & 15u, base = e >> 16;
                             const uint32_t xb = k == 1 ? sym : xt[sym] >> 24;
-                            t.e[u] = nb | ((nb + xb) << 5) | (sym << 12) | (base << 23);
+                            t.e[u] = nb | (((0u - (nb + xb)) & 127u) << 5) | (sym << 12) | (base << 23);
                         }
                     }
                 }
@@ -1308,32 +1309,37 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     const uint32_t n_upd = i0 + cn == nseq ? cn - 1u : cn;
                     const int32_t T0 = (int32_t)s.lo + s.avail, Tmin = (int32_t)s.lo;
                     int32_t T = T0;
-                    uint32_t my_al = 0, my_ao = 0, my_am = 0;
+                    // sequence j's three states are parked in LDS (xpar[3j..]: the copy phase's parameters, dead here) for lane j
+                    uint32_t *const sst = L.xpar;
 #ifndef CHIP_ZSTD_NO_ASM_CHAIN
                     // (the hand-written loop addresses the tables by their offsets in ZLds: L is the kernel's only LDS object, at 0)
                     bool asm_chain = rdfirst((uint32_t)(uintptr_t)(__attribute__((address_space(3))) ZLds *)&L) == 0u;
+#else
+                    bool asm_chain = false;
 #endif
-                    __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
-                    uint32_t j = 0;
-                    while (rdfirst(j) < n_upd) {
-#ifndef CHIP_ZSTD_NO_ASM_CHAIN
-                        if (asm_chain) {
+                    const uint32_t al0 = al, ao0 = ao, am0 = am;
+                    uint32_t my_al = 0, my_ao = 0, my_am = 0, my_el = 0, my_eo = 0, my_em = 0, my_tot = 0;
+                    for (;;) {
+                        LSYNC();  // the copy phase of the chunk before is done with xpar
+                        __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
+                        T = T0;
+                        dec_bad = 64;
+                        if (asm_chain && n_upd) {
                             // The loop below, written by hand: everything stays in vector registers (the values are the same in
-                            // every lane), so the dependent path of a sequence is LDS round trip -> v_add3 -> v_bfe -> v_sub ->
-                            // shift -> v_bfe -> v_lshl_add -> next LDS read, with no detour over the scalar unit.  Every
+                            // every lane), so the dependent path of a sequence is LDS round trip -> v_add3 -> v_bfe_i32 ->
+                            // v_lshrrev_b64 -> v_bfe -> v_lshl_add -> next LDS read, with no detour over the scalar unit.  Every
                             // state is followed at once by the read of its entry, the window words of the next sequence are requested
-                            // as soon as its bit position is known.  The loop has no data-dependent exit: a sequence whose bits do not
-                            // fit one 64-bit view (seen afterwards in the maximum of the bit counts) sends the whole chunk to the C++
-                            // loop below, and a position below the stream's start is found by the lanes in the parallel part.
-                            uint32_t tp = (uint32_t)(T - 64 - 32 * s.win0), mx = 0;
+                            // as soon as its bit position is known.  19 VALU per sequence (the kernel is bound by vector issue).  The
+                            // loop has no data-dependent exit: a sequence whose bits do not fit one 64-bit view is seen afterwards by
+                            // the lane that finishes it and sends the whole chunk through the C++ loop below; a position below the
+                            // stream's start is found in the parallel part.  (v126 / v127: the 64-bit view, a register pair by name.)
+                            uint32_t tp = (uint32_t)(T - 64 - 32 * s.win0), j = 0;
                             const uint32_t n_upd_s = rdfirst(n_upd);
-                            const uint32_t al0 = al, ao0 = ao, am0 = am, j0 = j;
-                            uint32_t ta, td0, td1, td2, tel, teo, tem, tS, ttot, thi, tlo, tx, tW, tq;
+                            uint32_t ta, td0, td1, td2, tel, teo, tem, tS, txs, tq, tja = (uint32_t)offsetof(ZLds, xpar);
                             asm volatile(
                                 // reads of the first sequence
-                                "v_ashrrev_i32 %[a], 5, %[tp]\n\t"
-                                "v_max_i32 %[a], 0, %[a]\n\t"
-                                "v_lshlrev_b32 %[a], 2, %[a]\n\t"
+                                "v_lshrrev_b32 %[a], 3, %[tp]\n\t"
+                                "v_and_b32 %[a], 0x3fc, %[a]\n\t"
                                 "ds_read_b32 %[d0], %[a] offset:%[OW0]\n\t"
                                 "ds_read_b32 %[d1], %[a] offset:%[OW1]\n\t"
                                 "ds_read_b32 %[d2], %[a] offset:%[OW2]\n\t"
@@ -1341,40 +1347,33 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                                 "ds_read_b32 %[em], %[am] offset:%[OM]\n\t"
                                 "ds_read_b32 %[eo], %[ao] offset:%[OO]\n\t"
                                 "1:\n\t"
-                                "v_cmp_eq_u32 vcc, %[j], %[lane]\n\t"
-                                "v_cndmask_b32 %[myl], %[myl], %[al], vcc\n\t"
-                                "v_cndmask_b32 %[myo], %[myo], %[ao], vcc\n\t"
-                                "v_cndmask_b32 %[mym], %[mym], %[am], vcc\n\t"
-                                "s_waitcnt lgkmcnt(0)\n\t"
+                                "ds_write2_b32 %[ja], %[al], %[am] offset1:1\n\t"
+                                "ds_write_b32 %[ja], %[ao] offset:8\n\t"
+                                "v_add_u32 %[ja], 12, %[ja]\n\t"
+                                "s_waitcnt lgkmcnt(2)\n\t"
                                 "v_add3_u32 %[S], %[el], %[eo], %[em]\n\t"
-                                "v_bfe_u32 %[tot], %[S], 5, 7\n\t"
-                                "v_sub_u32 %[x], 64, %[tot]\n\t"
-                                "v_alignbit_b32 %[hi], %[d2], %[d1], %[tp]\n\t"
-                                "v_alignbit_b32 %[lo], %[d1], %[d0], %[tp]\n\t"
-                                "v_alignbit_b32 %[lo], %[hi], %[lo], %[x]\n\t"
-                                "v_lshrrev_b32 %[hi], %[x], %[hi]\n\t"
-                                "v_cmp_gt_u32 vcc, 32, %[x]\n\t"
-                                "v_cndmask_b32 %[W], %[hi], %[lo], vcc\n\t"
+                                "v_bfe_i32 %[xs], %[S], 5, 7\n\t"
+                                "v_alignbit_b32 v127, %[d2], %[d1], %[tp]\n\t"
+                                "v_alignbit_b32 v126, %[d1], %[d0], %[tp]\n\t"
+                                "v_lshrrev_b64 v[126:127], %[xs], v[126:127]\n\t"
                                 // the next states, each followed at once by the read of its entry
                                 "v_add_u32 %[q], %[eo], %[em]\n\t"
-                                "v_bfe_u32 %[q], %[W], %[q], %[el]\n\t"
+                                "v_bfe_u32 %[q], v126, %[q], %[el]\n\t"
                                 "v_lshrrev_b32 %[S], 21, %[el]\n\t"
                                 "v_lshl_add_u32 %[al], %[q], 2, %[S]\n\t"
                                 "ds_read_b32 %[el], %[al] offset:%[OL]\n\t"
-                                "v_bfe_u32 %[q], %[W], %[eo], %[em]\n\t"
+                                "v_bfe_u32 %[q], v126, %[eo], %[em]\n\t"
                                 "v_lshrrev_b32 %[S], 21, %[em]\n\t"
                                 "v_lshl_add_u32 %[am], %[q], 2, %[S]\n\t"
                                 "ds_read_b32 %[em], %[am] offset:%[OM]\n\t"
-                                "v_bfe_u32 %[q], %[W], 0, %[eo]\n\t"
+                                "v_bfe_u32 %[q], v126, 0, %[eo]\n\t"
                                 "v_lshrrev_b32 %[S], 21, %[eo]\n\t"
                                 "v_lshl_add_u32 %[ao], %[q], 2, %[S]\n\t"
                                 "ds_read_b32 %[eo], %[ao] offset:%[OO]\n\t"
                                 // the bit position and the window words of the next sequence
-                                "v_max_u32 %[mx], %[mx], %[tot]\n\t"
-                                "v_sub_u32 %[tp], %[tp], %[tot]\n\t"
-                                "v_ashrrev_i32 %[a], 5, %[tp]\n\t"
-                                "v_max_i32 %[a], 0, %[a]\n\t"
-                                "v_lshlrev_b32 %[a], 2, %[a]\n\t"
+                                "v_add_u32 %[tp], %[tp], %[xs]\n\t"
+                                "v_lshrrev_b32 %[a], 3, %[tp]\n\t"
+                                "v_and_b32 %[a], 0x3fc, %[a]\n\t"
                                 "ds_read_b32 %[d0], %[a] offset:%[OW0]\n\t"
                                 "ds_read_b32 %[d1], %[a] offset:%[OW1]\n\t"
                                 "ds_read_b32 %[d2], %[a] offset:%[OW2]\n\t"
@@ -1382,74 +1381,94 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                                 "s_cmp_lt_u32 %[j], %[n]\n\t"
                                 "s_cbranch_scc1 1b\n\t"
                                 "s_waitcnt lgkmcnt(0)"
-                                : [al] "+v"(al), [ao] "+v"(ao), [am] "+v"(am), [myl] "+v"(my_al), [myo] "+v"(my_ao), [mym] "+v"(my_am), [tp] "+v"(tp),
-                                  [mx] "+v"(mx), [j] "+s"(j), [a] "=&v"(ta), [d0] "=&v"(td0), [d1] "=&v"(td1), [d2] "=&v"(td2), [el] "=&v"(tel),
-                                  [eo] "=&v"(teo), [em] "=&v"(tem), [S] "=&v"(tS), [tot] "=&v"(ttot), [hi] "=&v"(thi), [lo] "=&v"(tlo), [x] "=&v"(tx),
-                                  [W] "=&v"(tW), [q] "=&v"(tq)
-                                : [n] "s"(n_upd_s), [lane] "v"(lane), [OL] "n"(offsetof(ZLds, ll)), [OO] "n"(offsetof(ZLds, of)),
-                                  [OM] "n"(offsetof(ZLds, ml)), [OW0] "n"(offsetof(ZLds, seqwin)), [OW1] "n"(offsetof(ZLds, seqwin) + 4),
-                                  [OW2] "n"(offsetof(ZLds, seqwin) + 8)
-                                : "vcc", "scc", "memory");
-#ifdef CHIP_EXP_FORCE_FALLBACK  // test hook: every chunk takes the way back through the C++ loop
-                            if (rdfirst(mx) > 1000u) {
-#else
-                            if (rdfirst(mx) <= 64u) {
-#endif
-                                T = (int32_t)tp + 64 + 32 * s.win0;
-                                break;
+                                : [al] "+v"(al), [ao] "+v"(ao), [am] "+v"(am), [tp] "+v"(tp), [ja] "+v"(tja), [j] "+s"(j), [a] "=&v"(ta), [d0] "=&v"(td0),
+                                  [d1] "=&v"(td1), [d2] "=&v"(td2), [el] "=&v"(tel), [eo] "=&v"(teo), [em] "=&v"(tem), [S] "=&v"(tS), [xs] "=&v"(txs),
+                                  [q] "=&v"(tq)
+                                : [n] "s"(n_upd_s), [OL] "n"(offsetof(ZLds, ll)), [OO] "n"(offsetof(ZLds, of)), [OM] "n"(offsetof(ZLds, ml)),
+                                  [OW0] "n"(offsetof(ZLds, seqwin)), [OW1] "n"(offsetof(ZLds, seqwin) + 4), [OW2] "n"(offsetof(ZLds, seqwin) + 8)
+                                : "v126", "v127", "scc", "memory");
+                            T = (int32_t)tp + 64 + 32 * s.win0;
+                        } else {
+                            for (uint32_t j = 0; j < n_upd; j++) {
+                                int32_t wi = ((T - 64) >> 5) - s.win0;
+                                wi = wi < 0 ? 0 : wi;
+                                const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
+                                const uint32_t el = *(const uint32_t *)((const char *)L.ll.e + al), eo = *(const uint32_t *)((const char *)L.of.e + ao),
+                                               em = *(const uint32_t *)((const char *)L.ml.e + am);
+                                if (lane == 0) {  // lane j finishes sequence j
+                                    sst[3 * j] = al;
+                                    sst[3 * j + 1] = am;
+                                    sst[3 * j + 2] = ao;
+                                }
+                                const uint32_t S = el + eo + em;  // [4:0] the three state-bit counts, [11:5] minus (those + the extra bits)
+                                const uint32_t tot = (0u - (S >> 5)) & 127u;
+                                uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)T), wlo = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)T);
+                                uint32_t x = 64u - tot;
+                                if (tot > 64u) {
+                                    // rare: extras and state bits do not fit one 64-bit view; take a second one below the extras
+                                    const uint32_t n3 = S & 31u;
+                                    const int32_t q2 = T - (int32_t)(tot - n3) - 64;
+                                    int32_t w2 = (q2 >> 5) - s.win0;
+                                    w2 = w2 < 0 ? 0 : w2;
+                                    const uint32_t e0 = L.seqwin[w2], e1 = L.seqwin[w2 + 1], e2 = L.seqwin[w2 + 2];
+                                    whi = __builtin_amdgcn_alignbit(e2, e1, (uint32_t)q2);
+                                    wlo = __builtin_amdgcn_alignbit(e1, e0, (uint32_t)q2);
+                                    x = 64u - n3;
+                                }
+                                const uint32_t W = (uint32_t)((((uint64_t)whi << 32) | wlo) >> (x & 63u));  // LL, ML, OF state bits, OF lowest
+                                // next state = baseline + bits; entry bits [22:18] are zero, so entry >> 21 is the baseline times four
+                                al = lshl2_add(__builtin_amdgcn_ubfe(W, eo + em, el), el >> 21);
+                                am = lshl2_add(__builtin_amdgcn_ubfe(W, eo, em), em >> 21);
+                                ao = lshl2_add(__builtin_amdgcn_ubfe(W, 0, eo), eo >> 21);
+                                T -= (int32_t)tot;
+                                if (T < Tmin) {
+                                    dec_bad = j;
+                                    break;
+                                }
                             }
-                            // rare: some sequence's bits did not fit one 64-bit view -- the states after it are wrong: the chunk is
-                            // done again by the loop below
+                        }
+                        if (dec_bad == 64 && n_upd < cn) {  // the block's last sequence: extras only, no state update
+                            const uint32_t S = *(const uint32_t *)((const char *)L.ll.e + al) + *(const uint32_t *)((const char *)L.of.e + ao) +
+                                               *(const uint32_t *)((const char *)L.ml.e + am);
+                            if (lane == 0) {
+                                sst[3 * n_upd] = al;
+                                sst[3 * n_upd + 1] = am;
+                                sst[3 * n_upd + 2] = ao;
+                            }
+                            T -= (int32_t)(((0u - (S >> 5)) & 127u) - (S & 31u));
+                            if (T < Tmin) dec_bad = n_upd;
+                        }
+                        __builtin_amdgcn_s_setprio(0);
+                        LSYNC();
+                        // lane j takes sequence j's states and reads its entries again
+                        const bool have = lane < cn && lane < dec_bad;
+                        my_el = my_eo = my_em = my_tot = 0;
+                        uint32_t full_tot = 0;
+                        if (have) {
+                            my_al = sst[3 * lane];
+                            my_am = sst[3 * lane + 1];
+                            my_ao = sst[3 * lane + 2];
+                            my_el = *(const uint32_t *)((const char *)L.ll.e + my_al);
+                            my_eo = *(const uint32_t *)((const char *)L.of.e + my_ao);
+                            my_em = *(const uint32_t *)((const char *)L.ml.e + my_am);
+                            const uint32_t S = my_el + my_eo + my_em;
+                            full_tot = my_tot = (0u - (S >> 5)) & 127u;
+                            if (i0 + lane + 1 == nseq) my_tot -= S & 31u;
+                        }
+#ifdef CHIP_EXP_FORCE_FALLBACK  // test hook: every chunk takes the way back through the C++ loop
+                        if (asm_chain) {
+#else
+                        if (asm_chain && __any(lane < n_upd && full_tot > 64u)) {
+#endif
+                            // rare: some sequence's bits did not fit one 64-bit view -- the states behind it are wrong: the chunk is
+                            // done again by the C++ loop
                             al = al0;
                             ao = ao0;
                             am = am0;
-                            j = j0;
                             asm_chain = false;
+                            continue;
                         }
-#endif
-                        int32_t wi = ((T - 64) >> 5) - s.win0;
-                        wi = wi < 0 ? 0 : wi;
-                        const uint32_t d0 = L.seqwin[wi], d1 = L.seqwin[wi + 1], d2 = L.seqwin[wi + 2];
-                        const uint32_t el = *(const uint32_t *)((const char *)L.ll.e + al), eo = *(const uint32_t *)((const char *)L.of.e + ao),
-                                       em = *(const uint32_t *)((const char *)L.ml.e + am);
-                        my_al = lane == j ? al : my_al;  // lane j finishes sequence j
-                        my_ao = lane == j ? ao : my_ao;
-                        my_am = lane == j ? am : my_am;
-                        const uint32_t S = el + eo + em;  // [4:0] the three state-bit counts, [11:5] those + the extra bits
-                        const uint32_t tot = (S >> 5) & 127u;
-                        uint32_t whi = __builtin_amdgcn_alignbit(d2, d1, (uint32_t)T), wlo = __builtin_amdgcn_alignbit(d1, d0, (uint32_t)T);
-                        uint32_t x = 64u - tot;
-                        if (tot > 64u) {
-                            // rare: extras and state bits do not fit one 64-bit view; take a second one below the extras
-                            const uint32_t n3 = S & 31u;
-                            const int32_t q2 = T - (int32_t)(tot - n3) - 64;
-                            int32_t w2 = (q2 >> 5) - s.win0;
-                            w2 = w2 < 0 ? 0 : w2;
-                            const uint32_t e0 = L.seqwin[w2], e1 = L.seqwin[w2 + 1], e2 = L.seqwin[w2 + 2];
-                            whi = __builtin_amdgcn_alignbit(e2, e1, (uint32_t)q2);
-                            wlo = __builtin_amdgcn_alignbit(e1, e0, (uint32_t)q2);
-                            x = 64u - n3;
-                        }
-                        const uint32_t W = (uint32_t)((((uint64_t)whi << 32) | wlo) >> (x & 63u));  // LL, ML, OF state bits, OF lowest
-                        // next state = baseline + bits; entry bits [22:18] are zero, so entry >> 21 is the baseline times four
-                        al = lshl2_add(__builtin_amdgcn_ubfe(W, eo + em, el), el >> 21);
-                        am = lshl2_add(__builtin_amdgcn_ubfe(W, eo, em), em >> 21);
-                        ao = lshl2_add(__builtin_amdgcn_ubfe(W, 0, eo), eo >> 21);
-                        T -= (int32_t)tot;
-                        if (T < Tmin) {
-                            dec_bad = j;
-                            break;
-                        }
-                        j++;
-                    }
-                    if (dec_bad == 64 && n_upd < cn) {  // the block's last sequence: extras only, no state update
-                        const uint32_t S = *(const uint32_t *)((const char *)L.ll.e + al) + *(const uint32_t *)((const char *)L.of.e + ao) +
-                                           *(const uint32_t *)((const char *)L.ml.e + am);
-                        my_al = lane == n_upd ? al : my_al;
-                        my_ao = lane == n_upd ? ao : my_ao;
-                        my_am = lane == n_upd ? am : my_am;
-                        T -= (int32_t)(((S >> 5) & 127u) - (S & 31u));
-                        if (T < Tmin) dec_bad = n_upd;
+                        break;
                     }
                     __builtin_amdgcn_s_setprio(0);
                     s.avail = T - (int32_t)s.lo;
@@ -1461,15 +1480,6 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t ov = 4;
                     {
                         const bool have = lane < cn && lane < dec_bad;
-                        uint32_t my_el = 0, my_eo = 0, my_em = 0, my_tot = 0;
-                        if (have) {
-                            my_el = *(const uint32_t *)((const char *)L.ll.e + my_al);
-                            my_eo = *(const uint32_t *)((const char *)L.of.e + my_ao);
-                            my_em = *(const uint32_t *)((const char *)L.ml.e + my_am);
-                            const uint32_t S = my_el + my_eo + my_em;
-                            my_tot = (S >> 5) & 127u;
-                            if (i0 + lane + 1 == nseq) my_tot -= S & 31u;
-                        }
                         const uint32_t tot_incl = wave_incl_scan(my_tot);
                         const int32_t my_top = T0 - (int32_t)(tot_incl - my_tot);
                         // the first sequence that reads below the stream's start is the corrupt one (the chain itself ran on)
@@ -1481,7 +1491,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         const bool mine = have && lane < dec_bad;
                         if (mine) {
                             const uint32_t oc = (my_eo >> 12) & 63u, mc = (my_em >> 12) & 63u, lc = (my_el >> 12) & 63u;
-                            const uint32_t xl = ((my_el >> 5) & 127u) - (my_el & 31u), xm = ((my_em >> 5) & 127u) - (my_em & 31u);
+                            const uint32_t xl = ((0u - (my_el >> 5)) & 127u) - (my_el & 31u), xm = ((0u - (my_em >> 5)) & 127u) - (my_em & 31u);
                             const int32_t q = my_top - 64;
                             int32_t wi = (q >> 5) - s.win0;
                             wi = wi < 0 ? 0 : (wi > 253 ? 253 : wi);
