@@ -54,15 +54,22 @@ struct alignas(16) ZLds {
     FseTab ll, ml;
     FseTabOf of;
     uint32_t huf_bits, huf_valid;
-    uint8_t weights[256];
-    int16_t norm[64];
-    uint16_t next[64];
-    FseTabWt wt;  // FSE table of the Huffman weights
-    uint32_t lltab[36], mltab[53];  // sequence code -> baseline | extra bits << 24 (kept on chip: read once per sequence)
-    uint32_t seqwin[256];  // staged window of the sequence bitstream (read backward)
-    uint32_t xheads[64];   // copy phase: owner of every byte of a 256-byte step
-    uint32_t xpar[192];    // copy phase: per-item parameters
+    union {
+        struct {  // table builds only (between them and the next build everything below is free for the phases)
+            uint8_t weights[256];
+            int16_t norm[64];
+            uint16_t next[64];
+            FseTabWt wt;  // FSE table of the Huffman weights
+        };
+        uint32_t seqwin[256];  // staged window of the sequence bitstream (read backward); literal decode: boundary rows (with xheads, xpar)
+    };
+    uint32_t xheads[64];   // copy phase: owner of every byte of a 256-byte step; table builds: running counts
+    uint32_t xpar[192];    // copy phase: per-item parameters; state chain: the three states of every sequence of a chunk
+    // sequence code -> baseline | extra bits << 24 for the codes that carry extra bits (LL 16.., ML 32..; below them the
+    // baseline is the code itself, plus 3 for match lengths): read once per sequence
+    uint32_t lltab[20], mltab[21];
 };
+static_assert(sizeof(ZLds) <= 11520, "fourteen waves per CU (LDS is granted in 1280-byte steps)");
 
 // Streaming decoder only (BatchArgs::resume, one unit): checkpoint written after every completed block -- ZRES_HDR header words
 // ([0] 1 + input bytes consumed (0 = none), [1] output bytes in the buffer, [2..4] repeat offsets, [5] flags: 1 checksum, 2 content
@@ -246,9 +253,6 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
     const uint32_t lane = lane_id(), k = lane & 15u, g0 = lane & ~15u;
     const uint32_t hbits = L.huf_bits;
     uint32_t *const rows = L.seqwin;                 // [word][lane]
-    uint32_t *const flags = (uint32_t *)L.weights;   // 64 words, dead once the Huffman table exists
-    uint32_t *const sidx = (uint32_t *)L.norm;       // 64 words (norm + next)
-    uint32_t *const soff = L.xpar + 128;             // 64 words behind the rows
     enum : uint32_t { H_IDLE = 0, H_JOIN = 1, H_LIMIT = 2, H_END = 3, H_BAD = 4 };
     bool bad = false;
     bool live = true;  // the stream still has symbols to find
@@ -312,36 +316,35 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
                 a_join += __popc(rows[w * 64 + jl] & below);
             }
         }
-        bool on = live && k == 0;
-        uint32_t jump = nxt;
+        // The n-th piece of a stream = the lane reached from the group's first lane by n joins: powers of the join map by doubling,
+        // composed along the bits of n (ds_bpermute: registers only, no barriers); the map's fixed points end the stream.  Lane k of
+        // a group then works on the stream's k-th piece, whichever lane walked it: stream order, so one prefix sum places the pieces.
+        auto gather = [](uint32_t x, uint32_t src) { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src << 2), (int)x); };
+        uint32_t node = g0;
+        {
+            uint32_t pw = nxt < 64u ? nxt : lane;
 #pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            flags[lane] = 0;
-            WSYNC();
-            if (on && jump < 64u) flags[jump] = 1;
-            WSYNC();
-            on = on || flags[lane] != 0;
-            const uint32_t j2 = (uint32_t)__shfl((int)jump, (int)(jump & 63u), 64);
-            jump = jump < 64u ? j2 : 64u;
-            WSYNC();
+            for (int rd = 0; rd < 4; rd++) {
+                const uint32_t nx = gather(pw, node);
+                if ((k >> rd) & 1u) node = nx;
+                pw = gather(pw, pw);
+            }
         }
-        if (on && nxt < 64u) {
-            sidx[nxt] = a_join;
-            soff[nxt] = rstop;
-        }
-        WSYNC();
-        const uint32_t a0 = k == 0 ? 0u : sidx[lane];
-        const uint32_t pstart = k == 0 ? 0u : soff[lane];  // offset below the stream top where this lane's piece starts
-        const uint32_t cnt = (on && nst > a0) ? nst - a0 : 0u;
+        const uint32_t prev = wave_shr1(node);  // the piece before (k = 0: none)
+        const bool on = live && (k == 0 || node != prev);  // lanes behind the stream's end repeat its last piece
+        const uint32_t e_nst = gather(nst, node);
+        const uint32_t g_a0 = gather(a_join, prev), g_ps = gather(rstop, prev);  // (every lane takes part: a lane switched off cannot be read)
+        const uint32_t a0 = k == 0 ? 0u : g_a0;
+        const uint32_t pstart = k == 0 ? 0u : g_ps;  // offset below the stream top where this piece starts
+        const uint32_t cnt = (on && e_nst > a0) ? e_nst - a0 : 0u;
         const uint32_t incl = wave_incl_scan(cnt);
         const uint32_t below = (uint32_t)__shfl((int)incl, (int)((g0 - 1u) & 63u), 64);  // every lane takes part: the source lane must be active
         const uint32_t gbase = g0 ? below : 0u;
         const uint32_t first = incl - cnt - gbase;
         const uint32_t total = (uint32_t)__shfl((int)incl, (int)(g0 + 15u), 64) - gbase;
-        // the stream's chain ends in its highest lane that is on it
-        const uint64_t onm = __ballot(on) & (0xffffull << g0);
-        const uint32_t lz = onm ? 63u - (uint32_t)__clzll((long long)onm) : g0;
-        const uint32_t rz = (uint32_t)__shfl((int)reason, (int)lz, 64), sz = (uint32_t)__shfl((int)rstop, (int)lz, 64);
+        // the stream's chain ends in the lane its last piece lies in
+        const uint32_t lz = gather(node, g0 + 15u);
+        const uint32_t rz = gather(reason, lz), sz = gather(rstop, lz);
         // ---- second pass: the owned symbols, stored
         {
             HufBits h2;
@@ -851,7 +854,7 @@ __device__ void wave_match_copy(uint8_t *dst, uint32_t offset, uint32_t n)
 }
 
 #ifndef CHIP_ZSTD_WAVES
-#define CHIP_ZSTD_WAVES 3  // waves per SIMD the register budget is set for; LDS (12.4 KB) allows 12 per CU
+#define CHIP_ZSTD_WAVES 3  // waves per SIMD the register budget is set for (157 VGPRs); at 4 the LDS (11.2 KB) would allow 14 waves per CU, but 34 registers spill: 5.15 against 4.98 ms
 #endif
 __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, int wlog_max)
 {
@@ -881,8 +884,8 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         L.huf_valid = 0;
         L.ll.valid = L.of.valid = L.ml.valid = 0;
     }
-    if (lane < 36) L.lltab[lane] = LL_BASE[lane] | ((uint32_t)LL_BITS[lane] << 24);
-    if (lane < 53) L.mltab[lane] = ML_BASE[lane] | ((uint32_t)ML_BITS[lane] << 24);
+    if (lane < 20) L.lltab[lane] = LL_BASE[16 + lane] | ((uint32_t)LL_BITS[16 + lane] << 24);
+    if (lane < 21) L.mltab[lane] = ML_BASE[32 + lane] | ((uint32_t)ML_BITS[32 + lane] << 24);
     WSYNC();
 
 #define ZFAIL(code) do { status = -(code); goto done; } while (0)
@@ -1265,10 +1268,11 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         // the 64-bit view to the bottom), [17:12] the code, [31:23] the baseline of the next state.
                         WSYNC();
                         const uint32_t *xt = k == 0 ? L.lltab : L.mltab;
+                        const uint32_t xt0 = k == 0 ? 16u : 32u;  // codes below carry no extra bits
                         const uint32_t size = 1u << *t.al;
                         for (uint32_t u = lane; u < size; u += 64) {
                             const uint32_t e = t.e[u], sym = e & 63u, nb = (e >> 6) & 15u, base = e >> 16;
-                            const uint32_t xb = k == 1 ? sym : xt[sym] >> 24;
+                            const uint32_t xb = k == 1 ? sym : sym < xt0 ? 0u : xt[sym - xt0] >> 24;
                             t.e[u] = nb | (((0u - (nb + xb)) & 127u) << 5) | (sym << 12) | (base << 23);
                         }
                     }
@@ -1502,8 +1506,8 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             const uint32_t mlx = xm ? (uint32_t)((w64 << oc) >> (64u - xm)) : 0u;
                             const uint32_t llx = xl ? (uint32_t)((w64 << (oc + xm)) >> (64u - xl)) : 0u;
                             ov = (1u << oc) + obits;
-                            ml = (L.mltab[mc] & 0xffffffu) + mlx;
-                            ll = (L.lltab[lc] & 0xffffffu) + llx;
+                            ml = (mc < 32u ? mc + 3u : L.mltab[mc - 32u] & 0xffffffu) + mlx;
+                            ll = (lc < 16u ? lc : L.lltab[lc - 16u] & 0xffffffu) + llx;
                         }
                     }
                     // ---- offsets.  A sequence with a new offset (the usual case) is done in parallel; only the ones that
