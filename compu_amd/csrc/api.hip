@@ -1047,6 +1047,22 @@ chip_decode_result chip_decode(chip_decoder *d, const uint8_t *in, size_t in_len
         d->h_in_len -= giveback;
     }
     r.input_remain = (in_len - taken) + giveback;
+    if (d->format == CHIP_FMT_ZSTD) {
+        // src/decoder/zstd.rs:113-135: 0 -> Finished (frame done AND flushed); else a full output buffer -> NeedOutput,
+        // whatever else happened; else no error -> NeedInput; else the error
+        if (d->k_status == CHIP_FINISHED && d->delivered == d->k_out_len) {
+            d->done = true;
+            r.status = CHIP_FINISHED;
+        } else if (r.output_remain == 0 || d->delivered < d->k_out_len || d->k_status == CHIP_NEED_OUTPUT) {
+            r.status = CHIP_NEED_OUTPUT;
+        } else if (d->k_status == CHIP_NEED_INPUT || d->k_status == CHIP_FINISHED) {
+            r.status = CHIP_NEED_INPUT;
+        } else {
+            r.status = -1;
+            r.err = d->k_status;
+        }
+        return r;
+    }
     if (d->delivered < d->k_out_len || d->k_status == CHIP_NEED_OUTPUT) {
         r.status = CHIP_NEED_OUTPUT;
         return r;
