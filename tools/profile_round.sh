@@ -18,6 +18,12 @@ for wl in dynamic stored fixed mixed encode; do
 done
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d gpurun_out/${tag}_pmc_insts -o run --output-format csv -- python3 tools/prof_run.py dynamic 8192 3 > gpurun_out/${tag}_pmc_insts.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_insts/run_counter_collection.csv 8192 > gpurun_out/${tag}_pmc_insts.txt || true
+# the same instruction counters for the zstd kernel (8 192 frames) and the level-1 encoder (8 192 units)
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d gpurun_out/${tag}_pmc_insts_zstd -o run --output-format csv -- python3 tools/time_zstd.py 8192 > gpurun_out/${tag}_pmc_insts_zstd.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_insts_zstd/run_counter_collection.csv 8192 > gpurun_out/${tag}_pmc_insts_zstd.txt || true
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d gpurun_out/${tag}_pmc_insts_encode -o run --output-format csv -- python3 tools/prof_run.py encode 8192 3 > gpurun_out/${tag}_pmc_insts_encode.log 2>&1
+python3 tools/pmc_summary.py gpurun_out/${tag}_pmc_insts_encode/run_counter_collection.csv 8192 > gpurun_out/${tag}_pmc_insts_encode.txt || true
+echo "[profile] instruction counters done"
 # cfg5 at its per-GPU size (1 M frames over 8 GPUs = 131 072 per GPU): the line is kept as evidence that the size runs on one GPU
 python3 bench.py --workload mixed --units 131072 --steps 3 --warmup 1 --no-cpu --extra 0 > gpurun_out/${tag}_mixed_131072.json 2>> gpurun_out/${tag}_bench.log || true
 echo "[profile] done"

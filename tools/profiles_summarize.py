@@ -77,6 +77,9 @@ for wl, kernels in KERNELS.items():
 json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 if os.path.exists(os.path.join(G, f"{tag}_pmc_insts.txt")):
     open(os.path.join(P, f"{tag}_pmc_insts.txt"), "w").write(open(os.path.join(G, f"{tag}_pmc_insts.txt")).read())
+for extra in ("pmc_insts_zstd", "pmc_insts_encode"):
+    if os.path.exists(os.path.join(G, f"{tag}_{extra}.txt")):
+        open(os.path.join(P, f"{tag}_{extra}.txt"), "w").write(open(os.path.join(G, f"{tag}_{extra}.txt")).read())
 if os.path.exists(os.path.join(G, f"{tag}_bench.json")):
     open(os.path.join(P, f"{tag}_bench_rocprof_run.json"), "w").write(open(os.path.join(G, f"{tag}_bench.json")).read())
 if os.path.exists(os.path.join(G, f"{tag}_mixed_131072.json")):
