@@ -126,8 +126,10 @@ void chip_decoder_free(chip_decoder *d);
 /* Memory a streaming decoder holds right now: pinned host bytes (buffered input) and device bytes (input copy, decoded
  * output not yet handed on + the 32 KiB window, checkpoint).  An inflate stream keeps O(window + piece) whatever its
  * length: input in front of the last block boundary and output that has been handed on are dropped between calls (the
- * reference's state is ~40 KiB per decoder, src/decoder/zlib_ng.rs:29-55).  The kernel's token scratch (64 KiB per
- * streaming decoder) is not included. */
+ * reference's state is ~40 KiB per decoder, src/decoder/zlib_ng.rs:29-55).  A zstd stream keeps O(frame window + piece)
+ * the same way (ZSTD_decompressStream's own buffers, src/decoder/zstd.rs:98-136): the block checkpoint carries the running
+ * XXH64, output behind the window is dropped; a single-segment frame's window is its content size.  The inflate kernel's
+ * token scratch (64 KiB per streaming decoder) is not included. */
 void chip_decoder_footprint(const chip_decoder *d, size_t *pinned_bytes, size_t *device_bytes);
 /* describe_error_fn: src/decoder/zlib_ng.rs:118-123 (zError), src/decoder/zstd.rs:159-164
  * (ZSTD_getErrorName).  Never NULL for code 0 (tests/decoder.rs:74-76). */
