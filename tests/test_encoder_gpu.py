@@ -136,8 +136,15 @@ def test_batch_encode_matches_oracle_bytes(gpu, alice):
     for fmt in (-15, 15, 31):
         datas = []
         for it in range(120):
-            n = rnd.choice([0, 1, 3, 4, 5, 63, 64, 65, 100, 1000, 5000, 65535, 65536, 65537, 70000])
-            datas.append(_mk(rnd.randrange(5), n, rnd, alice))
+            # (sizes past 64 KiB: the hash table's 16-bit positions wrap; far copies alias positions 64 KiB apart)
+            n = rnd.choice([0, 1, 3, 4, 5, 63, 64, 65, 100, 1000, 5000, 65535, 65536, 65537, 70000, 131071, 200000, 400000])
+            kind = rnd.randrange(7)
+            if kind < 5:
+                datas.append(_mk(kind, n, rnd, alice))
+            else:  # a block repeated with a period of (or just off) 64 KiB: the slot's low 16 bits name the copy one period back
+                period = 65536 if kind == 5 else rnd.choice([65535, 65537, 70000, 32768, 32769])
+                blk = (alice * 2)[: period // 2] + rnd.randbytes(period - period // 2)
+                datas.append((blk * (n // period + 1))[:n])
         level = {-15: 1, 15: 0, 31: 1}[fmt]
         lens = np.array([len(d) for d in datas], np.int32)
         offs = np.zeros(len(datas), np.int64)
