@@ -47,6 +47,24 @@ def test_every_level_strategy_mode_round_trips(alice):
         assert len(comp) <= n + 5 * (n // 65535 + 1) + 6 * (n // 65472 + 1) + 5 + 18  # chip_encode_bound
 
 
+def test_sixteen_bit_table_positions_wrap_and_alias(alice):
+    """The match finder keeps the low 16 bits of a position per hash slot (oracle_deflate.c, header): inputs far past 64 KiB, and
+    inputs that repeat with a period of exactly / nearly 64 KiB (a slot then names the copy one period back, out of the window's
+    reach, or a position that merely shares its low bits), still give valid streams -- system zlib decodes them to the input -- and
+    find the matches that are there across the 64 KiB marks."""
+    rnd = random.Random(9)
+    for period in (65536, 65535, 65537, 70000, 32768, 32769, 131072):
+        blk = (alice * 2)[: period // 2] + rnd.randbytes(period - period // 2)
+        data = (blk * (500000 // period + 2))[:500000]
+        for level in (1, 3, 6):
+            comp = _enc(data, level=level)
+            assert zlib.decompress(comp, -15) == data, (period, level)
+    # (one position per slot: a copy is found if the slot has not been taken again since -- 2 000 positions back, yes)
+    noise = rnd.randbytes(2000)
+    once, many = len(_enc(noise, level=1)), len(_enc(noise * 100, level=1))  # 200 000 bytes: the copies lie on both sides of 64 KiB marks
+    assert many < once + 99 * 150, (once, many)
+
+
 def test_block_kinds_and_levels(alice):
     def first_btype(comp):
         return (comp[0] >> 1) & 3
