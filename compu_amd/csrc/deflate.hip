@@ -28,6 +28,7 @@ constexpr uint32_t MIN_MATCH = 4, MAX_MATCH = 258, MAX_DIST = 32768;
 constexpr int OUT_DW = 192;  // LDS bit buffer, dwords (a chunk adds at most 62); with the table and lentab: 10 240 B = sixteen waves per CU
 
 struct alignas(16) ELds {
+    static constexpr int WAYS = 1;
     static constexpr uint32_t OBUF = OUT_DW + 64;
     uint16_t table[1 << HASH_BITS];  // low 16 bits of the highest position with that hash (oracle_deflate.c states the rule)
     uint32_t obuf[OBUF];
@@ -166,9 +167,12 @@ constexpr uint32_t TOK_BLOCK = 65536;  // tokens per block (a 64 KiB unit is one
 constexpr uint32_t TOK_MATCH = 0x80000000u;
 __device__ __constant__ static const uint8_t CL_ORDER[20] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15, 0};
 
-struct alignas(16) DLds {
+// WAYS = positions kept per hash slot: 1 (levels 2..5), 2 (levels 6..9: the newest two; table[0] newest)
+template <int WAYS_>
+struct alignas(16) DLdsT {
+    static constexpr int WAYS = WAYS_;
     static constexpr uint32_t OBUF = 416;  // dwords; a group of 64 tokens adds at most 96
-    uint16_t table[1 << HASH_BITS];
+    uint16_t table[WAYS_ << HASH_BITS];
     uint32_t obuf[OBUF];
     uint32_t lfreq[288], dfreq[32], cfreq[20];
     union {
@@ -186,12 +190,16 @@ struct alignas(16) DLds {
     uint8_t ll[288], dl[32], cl[20];
     uint32_t lentab[256];  // per match length 3..258: length code 0..28 | extra-bit count << 8 | extra-bit value << 16
 };
+using DLds = DLdsT<1>;
+using DLds2 = DLdsT<2>;
 static_assert(sizeof(DLds) <= 19200, "eight waves per CU (LDS is granted in 1280-byte steps)");
+static_assert(sizeof(DLds2) <= 26880, "six waves per CU");
 
 // Code lengths of freq[0..n) (n <= 288) limited to maxbits into len[0..n): Huffman over (frequency, symbol)-sorted
 // leaves, two-queue merge with ties to the leaf; too deep -> all frequencies halved (rounding up) and rebuilt.
 // Sorting is a rank count (all lanes), the merge runs on lane 0, depths come from pointer jumping (all lanes).
-__device__ __forceinline__ void build_lengths(DLds &L, const uint32_t *freq, uint32_t n, uint32_t maxbits, uint8_t *len)
+template <class DL>
+__device__ __forceinline__ void build_lengths(DL &L, const uint32_t *freq, uint32_t n, uint32_t maxbits, uint8_t *len)
 {
     const uint32_t lane = lane_id();
     uint32_t f[5], m = 0;
@@ -343,7 +351,8 @@ __device__ __forceinline__ void canon_codes(const uint8_t *len, uint32_t n, uint
 }
 
 // one value of nb <= 48 bits per lane (nb = 0: none), appended in lane order
-__device__ __forceinline__ void put_lanes(DLds &L, uint32_t &nbits, uint64_t bits, uint32_t nb)
+template <class DL>
+__device__ __forceinline__ void put_lanes(DL &L, uint32_t &nbits, uint64_t bits, uint32_t nb)
 {
     const uint32_t incl = wave_incl_scan(nb);
     if (nb) {
@@ -402,7 +411,7 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
     const uint32_t *g32 = (const uint32_t *)(gin - mis);
     const uint32_t total_dw = (mis + n + 3u) >> 2;
 
-    for (uint32_t j = lane; j < (1u << HASH_BITS) / 2; j += 64) ((uint32_t *)L.table)[j] = 0;
+    for (uint32_t j = lane; j < (uint32_t)(LDS::WAYS << HASH_BITS) / 2; j += 64) ((uint32_t *)L.table)[j] = 0;
     for (uint32_t j = lane; j < LDS::OBUF; j += 64) L.obuf[j] = 0;
     for (uint32_t j = lane; j < 256; j += 64) {
         uint32_t lc, lext, lxv;
@@ -453,7 +462,11 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             uint32_t v, q;
             U128u qv, pv;  // 16 bytes at the candidate and at the position (lanes at least 16 bytes before the unit's end)
             bool has;
+            uint32_t q2;   // two ways: the slot's older position
+            U128u qv2;
+            bool has2;
         };
+        constexpr bool TWO = LDS::WAYS == 2;
         const uint32_t last_dw = total_dw ? total_dw - 1u : 0u;
         // 16-byte loads start at most here; a unit under 16 bytes reads the aligned 16 bytes around its start (same page) and ignores them
         const uint32_t wide_end = n >= 16 ? n - 16u : 0u;
@@ -475,15 +488,23 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 c.v = p < n ? __builtin_amdgcn_alignbit(i + 1 < total_dw ? vd1 : 0u, i < total_dw ? vd0 : 0u, (off & 3u) * 8u) : 0u;
             }
             fetch_v(p + 64u);
-            uint32_t h = 0;
-            c.has = false;
-            c.q = p;
+            uint32_t h = 0, old0 = 0;
+            c.has = c.has2 = false;
+            c.q = c.q2 = p;
             if (valid4) {
                 h = (c.v * 2654435761u) >> (32 - HASH_BITS);
-                const uint32_t dist = (p - L.table[h]) & 0xffffu;  // the nearest earlier position with the slot's low 16 bits
+                old0 = L.table[h];
+                const uint32_t dist = (p - old0) & 0xffffu;  // the nearest earlier position with the slot's low 16 bits
                 if (dist - 1u < MAX_DIST && dist <= p) {
                     c.has = true;
                     c.q = p - dist;
+                }
+                if constexpr (TWO) {
+                    const uint32_t dist2 = (p - L.table[(1u << HASH_BITS) + h]) & 0xffffu;
+                    if (dist2 - 1u < MAX_DIST && dist2 <= p && dist2 != dist) {
+                        c.has2 = true;
+                        c.q2 = p - dist2;
+                    }
                 }
                 // Z_RLE: the only candidate is the byte before (distance 1); Z_HUFFMAN_ONLY: none
                 if (rle) {
@@ -494,11 +515,16 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     c.has = false;
                     c.q = p;
                 }
+                if (rle || no_match) {
+                    c.has2 = false;
+                    c.q2 = p;
+                }
             }
             // one unaligned 16-byte load per side: a scattered load costs the L1 a tag lookup per lane and instruction
             // (every lane issues both loads, clamped into the unit, so that waiting for chunk c's bytes leaves chunk
             // c+1's in flight; lanes in the unit's last 15 bytes do not use them)
             c.qv = *(const U128u *)(gwide + (c.q < wide_end ? c.q : wide_end));
+            if constexpr (TWO) c.qv2 = *(const U128u *)(gwide + (c.q2 < wide_end ? c.q2 : wide_end));
             c.pv = *(const U128u *)(gwide + (p < wide_end ? p : wide_end));
             LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the loads stay in flight)
             // The highest position of a slot stands.  (LDS has no 16-bit maximum: all write, a lane that finds a lower lane of
@@ -510,6 +536,22 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 if (!__any(lost)) break;
                 if (lost) L.table[h] = (uint16_t)p;
             }
+            if constexpr (TWO) {
+                // the older way: the second highest position of the chunk in the slot, or what the newer way held before the chunk.
+                // The slot's winner puts the old value there, then the others settle their highest as above.
+                const bool winner = valid4 && ((L.table[h] - base) & 0xffffu) == lane;
+                uint16_t *const t2 = L.table + (1u << HASH_BITS);
+                if (winner) t2[h] = (uint16_t)old0;
+                LSYNC();
+                const bool second = valid4 && !winner;
+                if (second) t2[h] = (uint16_t)p;
+                for (;;) {
+                    LSYNC();
+                    const bool lost2 = second && ((t2[h] - base) & 0xffffu) < lane;  // (what a loser reads here a loser of this chunk wrote)
+                    if (!__any(lost2)) break;
+                    if (lost2) t2[h] = (uint16_t)p;
+                }
+            }
         };
         // one chunk: look the next one up (its loads fly while this one is worked on), measure, choose, emit
         auto step = [&](Cand &cur, Cand &nxt, const uint32_t base) __attribute__((always_inline)) {
@@ -517,14 +559,14 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             const uint32_t p = base + lane;
             uint32_t mlen = 0, mdist = 0;
             const uint32_t v = cur.v;
-            if (cur.has) {
-                const uint32_t q = cur.q;
+            // common prefix of the position with a candidate (its first 16 bytes in qv), 0 if under MIN_MATCH
+            auto measure = [&](const uint32_t q, const U128u &qv) __attribute__((always_inline)) {
                 const uint32_t lim = n - p < MAX_MATCH ? n - p : MAX_MATCH;
                 // the first 16 bytes of both sides arrived together: most candidates are decided right here
                 uint32_t k = 0;
                 bool diff = false;
                 if (p + 16 <= n) {
-                    k = first_diff16(cur.qv, cur.pv);
+                    k = first_diff16(qv, cur.pv);
                     diff = k < 16;
                 }
                 if (!diff) {
@@ -544,9 +586,19 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     }
                 }
                 if (k > lim) k = lim;
-                if (k >= MIN_MATCH) {
-                    mlen = k;
-                    mdist = p - q;
+                return k >= MIN_MATCH ? k : 0u;
+            };
+            if (cur.has) {
+                mlen = measure(cur.q, cur.qv);
+                mdist = mlen ? p - cur.q : 0u;
+            }
+            if constexpr (TWO) {
+                if (cur.has2) {  // the older position wins only with a longer match
+                    const uint32_t k2 = measure(cur.q2, cur.qv2);
+                    if (k2 > mlen) {
+                        mlen = k2;
+                        mdist = p - cur.q2;
+                    }
                 }
             }
             // greedy choice, left to right over the chunk: jump from selected match to selected match (a scalar
@@ -944,9 +996,9 @@ __global__ __launch_bounds__(64) void deflate_kernel(EncArgs a)
 }
 
 // Persistent grid (the token scratch is per resident wave): each wave takes the next unit from *next_unit.
-__global__ __launch_bounds__(64) void deflate_dyn_kernel(EncArgs a, uint32_t *scratch, uint32_t *next_unit)
+template <class DL>
+__device__ __forceinline__ void dyn_grid(const EncArgs &a, DL &L, uint32_t *scratch, uint32_t *next_unit)
 {
-    __shared__ DLds L;
     uint32_t *tokbuf = scratch + (size_t)blockIdx.x * TOK_BLOCK;
     for (;;) {
         uint32_t i = 0;
@@ -956,6 +1008,17 @@ __global__ __launch_bounds__(64) void deflate_dyn_kernel(EncArgs a, uint32_t *sc
         encode_unit<true>(a, i, L, tokbuf);
         WSYNC();  // the next unit reuses the LDS
     }
+}
+__global__ __launch_bounds__(64) void deflate_dyn_kernel(EncArgs a, uint32_t *scratch, uint32_t *next_unit)
+{
+    __shared__ DLds L;
+    dyn_grid(a, L, scratch, next_unit);
+}
+// levels 6..9: two positions per hash slot
+__global__ __launch_bounds__(64) void deflate_dyn2_kernel(EncArgs a, uint32_t *scratch, uint32_t *next_unit)
+{
+    __shared__ DLds2 L;
+    dyn_grid(a, L, scratch, next_unit);
 }
 
 // Token scratch and the unit counter of the dynamic-level launches, cached per (device, stream) like the
@@ -1054,7 +1117,8 @@ hipError_t launch_deflate_l1(const BatchArgs &b, int level, uint32_t flags, uint
         if (e != hipSuccess) return e;
         if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
         const uint32_t blocks = b.n < (uint32_t)sl.blocks ? b.n : (uint32_t)sl.blocks;
-        hipLaunchKernelGGL(deflate_dyn_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
+        if (level >= 6) hipLaunchKernelGGL(deflate_dyn2_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
+        else hipLaunchKernelGGL(deflate_dyn_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(deflate_kernel, dim3(b.n), dim3(64), 0, stream, a);

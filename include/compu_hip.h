@@ -228,7 +228,8 @@ typedef struct {
     int32_t mode;        /* CHIP_FMT_DEFLATE | CHIP_FMT_ZLIB | CHIP_FMT_GZIP (default Gzip, zlib_common.rs:33-37) */
     int32_t compression; /* 0..9, or -1 = zlib's default (6) as zlib_common.rs:96-103 allows: 0 stored blocks, 1 greedy
                           * match + one fixed-Huffman block, 2..9 the same match finder + dynamic-Huffman blocks,
-                          * 4..9 with lazy choice (a match gives way to a longer one at the next position) */
+                          * 4..9 with lazy choice (a match gives way to a longer one at the next position),
+                          * 6..9 with two candidate positions per hash slot (the older one wins with a longer match) */
     int32_t device;      /* HIP device ordinal, -1 = current */
     int32_t strategy;    /* CHIP_STRATEGY_*: HuffmanOnly emits no matches, Rle only distance-1 matches, Fixed forces the
                           * fixed code at every level (zlib's Z_FIXED); Default and Filtered are the same here */

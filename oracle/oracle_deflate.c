@@ -20,7 +20,8 @@
  * if four bytes there match.  Tokens are chosen
  * greedily left to right.  Level 1 (and Z_FIXED): emitted with the fixed Huffman code (RFC 1951
  * sec. 3.2.6); a segment whose fixed-Huffman form is not smaller than stored blocks is emitted stored.
- * Levels 2..9: dynamic-Huffman blocks (write_block below); from level 4 on the choice is lazy: a match
+ * Levels 2..9: dynamic-Huffman blocks (write_block below); from level 6 on a slot keeps its two newest
+ * positions and the older one is taken when its match is longer; from level 4 on the choice is lazy: a match
  * gives way to a longer one at the next position of the same chunk.  Level 0 = stored.
  */
 #include "oracle.h"
@@ -95,7 +96,7 @@ static size_t stored_size(size_t n, int sync)
 }
 
 /* ---- the match finder: one 64-position chunk -> tokens ---------------------------------------- */
-typedef struct { uint16_t table[1u << HASH_BITS]; size_t skip; } matcher;
+typedef struct { uint16_t table[1u << HASH_BITS]; uint16_t older[1u << HASH_BITS]; int ways; size_t skip; } matcher;
 
 #define TOK_MATCH 0x80000000u
 #define TOK_LEN(t) (((t) & 0xffu) + 3u)
@@ -127,9 +128,20 @@ static unsigned chunk_tokens(matcher *m, const uint8_t *in, size_t n, size_t bas
             while (k < lim && in[q + k] == in[p + k]) k++;
             if (k >= MIN_MATCH) { mlen[l] = (unsigned)k; mdist[l] = (unsigned)(p - q); }
         }
+        if (m->ways == 2 && strategy != 3 && strategy != 2) { /* the slot's older position: taken only with a longer match */
+            uint32_t d1 = ((uint32_t)p - table[h]) & 0xffffu, d2 = ((uint32_t)p - m->older[h]) & 0xffffu;
+            if (d2 != 0 && d2 <= MAX_DIST && d2 <= p && d2 != d1) {
+                size_t q = p - d2, lim = n - p < MAX_MATCH ? n - p : MAX_MATCH, k = 0;
+                while (k < lim && in[q + k] == in[p + k]) k++;
+                if (k >= MIN_MATCH && k > mlen[l]) { mlen[l] = (unsigned)k; mdist[l] = (unsigned)(p - q); }
+            }
+        }
     }
     for (unsigned l = 0; l < 64; l++)
-        if (hh[l] != 0xffffffffu) table[hh[l]] = (uint16_t)(base + l); /* ascending: the highest position stands */
+        if (hh[l] != 0xffffffffu) { /* ascending: the highest position stands, the one before it becomes the older way */
+            m->older[hh[l]] = table[hh[l]];
+            table[hh[l]] = (uint16_t)(base + l);
+        }
     size_t pos = m->skip;
     while (pos < 64 && base + pos < n) {
         /* lazy (levels 4..9, like zlib from level 4 on): a match gives way to a longer one at the next position of the chunk */
@@ -325,6 +337,7 @@ static size_t encode_segment_dynamic(const uint8_t *in, size_t n, uint8_t *out, 
 {
     bitw w = {out, cap, 0, 0, 0, 0};
     matcher *m = (matcher *)calloc(1, sizeof *m);
+    m->ways = level >= 6 ? 2 : 1;
     uint32_t *tok = (uint32_t *)malloc(TOK_BLOCK * sizeof(uint32_t));
     unsigned nt = 0;
     size_t from = 0, base = 0;
