@@ -411,13 +411,15 @@ public:
         if (from + n > cursor_) return false;
         return n == 0 || (chip_memcpy_d2h(dst, buf_ + from, n, nullptr) == CHIP_OK && chip_stream_sync(nullptr) == CHIP_OK);
     }
-    // chip_decode_batch with this buffer's spare capacity as the output: unit i lands at spare + out_off[i] (device
+    // chip_decode_batch[_ex] with this buffer's spare capacity as the output: unit i lands at spare + out_off[i] (device
     // arrays, as in chip_decode_batch); `span` bytes behind the cursor become part of the data.  Only enqueues.
+    // flags: CHIP_F_COMPU_STATUS reports every unit's status exactly as compu's decode_fn would (include/compu_hip.h).
     int decode_batch(int format, size_t n, const DeviceBuffer &in, const uint64_t *in_off, const uint32_t *in_len, const uint64_t *out_off,
-                     const uint32_t *out_cap, uint32_t *out_len, uint32_t *in_used, int32_t *status, size_t span, void *stream = nullptr)
+                     const uint32_t *out_cap, uint32_t *out_len, uint32_t *in_used, int32_t *status, size_t span, void *stream = nullptr,
+                     uint32_t flags = 0)
     {
         if (span > cap_ - cursor_) return CHIP_E_INVALID;
-        const int rc = chip_decode_batch(format, n, in.data(), in_off, in_len, buf_ + cursor_, out_off, out_cap, out_len, in_used, status, stream);
+        const int rc = chip_decode_batch_ex(format, flags, n, in.data(), in_off, in_len, buf_ + cursor_, out_off, out_cap, out_len, in_used, status, stream);
         if (rc == CHIP_OK) cursor_ += span;
         return rc;
     }
