@@ -1040,7 +1040,7 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
     const uint32_t total_dw = rdfirst(w.total_dw);
     GAS uint32_t *const myrow = rdfirst_gptr(rows_) + row_base(lane);
     uint16_t *const pool16 = (uint16_t *)L.pool;
-    const uint32_t D0 = B >> 5, base4 = 4u * D0;
+    const uint32_t D0 = B >> 5;
     WSYNC();  // the phase before (header parse, previous flush) is done with the window's place
     {
         // all loads of the window go out before the first LDS store waits for one
@@ -1072,16 +1072,22 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         hard = hard < sr_end ? hard : sr_end;
         hard = hard < end_bit ? hard : end_bit;
     }
-    uint32_t p = s0, nst = 0;
-    uint32_t jb = 0, z = 0, pn = s0;  // of the lane's last token: join bit, halt flags, end position
+    // Positions inside the walk count from the window's first bit (32 * D0): a position's byte address in the window and in the mark
+    // bits is then a shift and a mask.  q = position of the next token; a step adds the token's length to it before it knows whether
+    // the token can be taken -- a lane that drops out keeps the length (tl), and the token's start is q - tl.
+    const uint32_t wbase = 32u * D0;
+    const uint32_t own_end_r = own_end - wbase, hard_r = hard - wbase;
+    uint32_t q = s0 - wbase, tl = 0, nst = 0;
+    uint32_t jb = 0, z = 0;  // of the lane's last token: join bit, halt flags
     bool run = s0 < end_bit;
     // A token's work is straight-line code; a lane whose token cannot be taken (it joined another chain, met an end-of-block or
     // invalid code, or the token ends behind `hard`) drops out with jb / z / pn as that step left them: the reason is read off them
     // after the loop.
     auto token = [&](uint32_t &tok) -> bool {
-        const uint32_t a = ((p >> 3) & ~3u) - base4;
+        const uint32_t p = q;
+        const uint32_t a = (p >> 3) & ~3u;
         const uint32_t bit = 1u << (p & 31u);
-        const uint32_t mine = p < own_end ? bit : 0u;
+        const uint32_t mine = p < own_end_r ? bit : 0u;
         const uint32_t old = atomicOr((uint32_t *)((uint8_t *)L.w.bm + a), mine);
         jb = old & (bit - mine);  // a boundary of the segment's owner: from here on the two chains are one
         const uint32_t *wp = (const uint32_t *)((const uint8_t *)L.w.win + a);
@@ -1100,11 +1106,11 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         const uint32_t cl2 = m & 15u, eb2 = __builtin_amdgcn_ubfe(m, 4, 4);
         const uint32_t dm1 = (__builtin_amdgcn_ubfe(m, 8, 2) << eb2) + __builtin_amdgcn_ubfe(w2, cl2, eb2);
         z = (e & (F_HALT | F_INV)) | (m & D_BAD);
-        pn = p + n1 + cl2 + eb2;
-        if ((jb | z) != 0 || pn > hard) return false;
+        tl = n1 + cl2 + eb2;
+        q = p + tl;
+        if ((jb | z) != 0 || q > hard_r) return false;
         const uint32_t v = __builtin_amdgcn_ubfe(lo, e, e >> 5) + __builtin_amdgcn_ubfe(e, 16, 9);
         tok = (((dm1 << 10) | 512u) & msk) | v;
-        p = pn;
         nst++;
         return true;
     };
@@ -1131,6 +1137,10 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
         }
         if (nst > ng) *(GAS u32x4 *)(myrow + 8u * ng) = u32x4{t4[0], t4[1], t4[2], t4[3]};  // ng is a multiple of 4: row_word(ng)
     }
+    // back to stream positions: a lane that dropped out stands behind the token it did not take
+    const bool dropped = s0 < end_bit && !full;
+    const uint32_t pn = q + wbase;                     // end of the lane's last token (taken or not)
+    const uint32_t p = pn - (dropped ? tl : 0u);       // start of the token that was not taken / of the next one
     // why the lane's last token was not taken, in zlib's order of verdicts
     uint32_t why = R_LIMIT;  // the chain simply ends (limit reached, row full, or it never ran)
     if (s0 < end_bit && !full) {
