@@ -857,8 +857,7 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         const uint64_t m1 = m >> 1;
         const uint32_t k = __builtin_amdgcn_mbcnt_hi((uint32_t)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m1, base));
         const uint32_t d = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(k << 2), (int)pdelta);
-        uint32_t t = g + lane;
-        if (g + 64u > ntok) t = t < ntok ? t : ntok - 1u;  // (uniform: the batch's last group)
+        const uint32_t t = min(g + lane, ntok - 1u);  // (lanes behind the batch's end read its last token again)
         before += inside;
         gnext = g + 64u;
         const uint32_t krow = (t + d) & 0xffffu;  // the token's index in its lane's row
@@ -898,14 +897,13 @@ __device__ CHIP_PHASE_FN bool flush_tokens(WaveLds &L, const uint32_t *grow_, ui
         asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the load into slot_r has landed
         const uint32_t t = C.tok[64u * slot_r + lane];
         // token: [8:0] literal byte or match length, [9] match, [25:10] distance - 1
-        const uint32_t ism = (uint32_t)__builtin_amdgcn_sbfe((int)t, 9, 1);  // all ones for a match
-        const uint32_t tv = t & 0x1ffu;
-        const uint32_t len = tv & ism;
-        const uint32_t dist = __builtin_amdgcn_ubfe(t, 10, 16) + 1u;
-        const uint32_t val = (dist & ism) | (tv & ~ism);
+        // (a literal's byte is the token's low byte as it stands; length and distance are only formed where a match is queued)
+        const bool ismatch = (t & 512u) != 0;
+        const uint32_t len = ismatch ? t & 0x1ffu : 0u;
+        const uint32_t val = ismatch ? __builtin_amdgcn_ubfe(t, 10, 16) + 1u : t;  // distance, or the literal (low byte)
         const uint32_t left = ntok - c0;
-        uint32_t olen = len > 1u ? len : 1u;
-        if (left < 64u) olen = lane < left ? olen : 0u;  // (uniform: the last group of a batch)
+        uint32_t olen = ismatch ? len : 1u;
+        olen = lane < left ? olen : 0u;  // (only the last group of a batch has lanes behind the end)
         const uint32_t incl = wave_incl_scan(olen);
         const uint32_t start = run + incl - olen;
         const uint32_t total = rdlane(incl, 63u);
