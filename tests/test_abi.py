@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
     assert lib.chip_version().startswith(b"compu-hip")
     # library-level argument checks need no device
     assert lib.chip_decode_batch(12345, 1, None, None, None, None, None, None, None, None, None, None) == -101
+    # unknown option bits of the _ex entry point are refused before anything else is looked at
+    assert lib.chip_decode_batch_ex(-15, 2, 1, None, None, None, None, None, None, None, None, None, None) == -101
+    assert lib.chip_decode_batch_ex(-15, 0x80000001, 0, None, None, None, None, None, None, None, None, None, None) == -101
+    assert lib.chip_decode_batch_ex(-15, 1, 0, None, None, None, None, None, None, None, None, None, None) == 0  # an empty batch is fine
     assert lib.chip_encode_bound(31, 65536) >= 65536 + 18
 
 
