@@ -540,7 +540,23 @@ def test_concurrent_launches_from_two_host_threads(gpu):
         for _ in range(20):
             res[k] = compu_amd.decode_batch(-15, d_in, d_off, d_len, outs[k], ooff, caps)
 
-    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    # a third thread launches batches of growing size on the same stream: every growth frees and reallocates the cached token
+    # scratch, which the other threads' launches use -- lookup, counter reset and launch are one critical section
+    big_n = [64, 256, 1024, 2048, 4096]
+    big_out = gpu.zeros(max(big_n) * 65536, dtype=gpu.uint8, device=dev)
+    big_res = {}
+
+    def grow():
+        compu_amd.trim()  # start from no scratch at all
+        for m in big_n:
+            rep = (m + n - 1) // n
+            o = d_off.repeat(rep)[:m].contiguous()
+            l = d_len.repeat(rep)[:m].contiguous()
+            oo = gpu.arange(m, dtype=gpu.int64, device=dev) * 65536
+            cc = gpu.full((m,), 65536, dtype=gpu.int32, device=dev)
+            big_res[m] = compu_amd.decode_batch(-15, d_in, o, l, big_out, oo, cc)
+
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)] + [threading.Thread(target=grow)]
     for t in ts:
         t.start()
     for t in ts:
@@ -550,3 +566,7 @@ def test_concurrent_launches_from_two_host_threads(gpu):
         ol, iu, st = res[k]
         assert bool((st == 2).all()) and bool((ol == 65536).all())
         assert gpu.equal(outs[k], want)
+    for m, (ol, iu, st) in big_res.items():
+        assert bool((st == 2).all()) and bool((ol == 65536).all()), m
+    m = big_n[-1]
+    assert gpu.equal(big_out[: m * 65536].view(m // n, n * 65536), want.unsqueeze(0).expand(m // n, -1))
