@@ -64,6 +64,29 @@ struct BatchArgs {
 };
 constexpr uint32_t F_COMPU_STATUS = 1u;  // = CHIP_F_COMPU_STATUS
 
+// ---- the two-kernel inflate pipeline (inflate.hip: tokens_kernel, lz77.hip: lz77_kernel) -----------------------------------------
+// tokens_kernel decodes a unit's bit stream into 32-bit tokens in stream order (token arena in HBM) and leaves a record per unit;
+// lz77_kernel executes a unit's tokens in an LDS image of the unit's output (one workgroup per unit) and stores the image.  A unit
+// that does not end cleanly, or does not fit the image, goes to the one-kernel path (inflate_kernel) through a fallback list.
+// token: [8:0] literal byte, or match length 3..258; [9] match; [25:10] match distance - 1
+constexpr uint32_t PIPE_MAXSEG = 24;                     // segments of a unit's record
+constexpr uint32_t PIPE_REC_WORDS = 8 + 2 * PIPE_MAXSEG;  // words per unit record
+constexpr uint32_t PIPE_ARENA_WORDS = 16384;             // tokens_kernel takes arena space in pieces of this many words (>= 64 lanes x 256 row tokens)
+constexpr uint32_t PIPE_IMAGE_BYTES = 65536;             // lz77_kernel's image: units with more output take the one-kernel path
+// unit record: [0] state (PIPE_ST_*), [1] number of segments, [2] wrapper kind (0 raw, 1 zlib, 2 gzip), [3] the trailer's check value,
+// [4] gzip ISIZE, [5] input bytes used, [6..7] reserved; then per segment two words: [0] tokens: first word in the arena, stored
+// bytes: offset in the unit's input; [1] count (tokens / bytes) | PIPE_SEG_STORED
+constexpr uint32_t PIPE_ST_FALLBACK = 0, PIPE_ST_TOKENS = 1;
+constexpr uint32_t PIPE_SEG_STORED = 1u << 31;
+struct PipeScratch {
+    uint32_t *rec;         // PIPE_REC_WORDS per unit (indexed by unit)
+    uint32_t *arena;       // token arena
+    uint32_t arena_words;  // its size
+    uint32_t *counters;    // [0] tokens_kernel's unit counter, [1] arena words taken, [2] fallback count, [3] inflate_kernel's unit counter
+    uint32_t *fallback;    // unit indices for inflate_kernel (n entries)
+};
+hipError_t launch_lz77(const BatchArgs &a, const PipeScratch &p, hipStream_t stream);
+
 // launchers (each only enqueues on `stream`)
 hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream);
 hipError_t release_inflate_scratch();  // frees the cached token scratch of the current device (after a device sync)

@@ -18,6 +18,8 @@
 //   output itself).
 // The grid is persistent: waves take units from a counter, so the token scratch is one slot per resident wave.
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <utility>
@@ -697,14 +699,18 @@ __device__ __forceinline__ void round_issue(Round &r, const ChunkLds &C, const u
     r.glob = glob_ok && r.len != 0 && r.len <= COPY_LANE_MAX && sx + (int32_t)r.len <= (int32_t)mis;
     r.v0 = U128u{0, 0, 0, 0};
     r.v1 = U128u{0, 0, 0, 0};
+#ifndef CHIP_EXP_NO_GLOB  // ablation (wrong output): the LZ77 source fetches from HBM are left out
     if (r.glob) {
         const u32x4_u t = *(GAS const u32x4_u *)(base + sx);
         r.v0 = U128u{t.x, t.y, t.z, t.w};
     }
+#endif
+#ifndef CHIP_EXP_NO_GLOB
     if (r.glob && r.len > 16u) {
         const u32x4_u t = *(GAS const u32x4_u *)(base + sx + 16);
         r.v1 = U128u{t.x, t.y, t.z, t.w};
     }
+#endif
 }
 
 __device__ __forceinline__ void round_finish(const Round &r, const ChunkLds &C, const uint8_t *base, uint32_t mis STAT_PARAM)
@@ -1029,8 +1035,15 @@ enum : uint32_t { R_JOIN = 1, R_LIMIT = 2, R_EOB = 3, R_NEED_INPUT = 4, R_BAD = 
 
 // One super-round: stages the input from the true token boundary B on, walks 64 chains, finds the true stream among them and
 // leaves its description in L.fl.pk (ntok tokens in npieces pieces).  term_why / term_pos say how and where the stream ends.
+// (pl: lane n's view of the stream's n-th piece, for the tokens kernel -- the same numbers that go to L.fl.pk)
+struct PieceLane {
+    uint32_t node;   // lane whose row holds the piece
+    uint32_t e_a0;   // the piece's first token in that row
+    uint32_t cnt;    // its tokens (0: no n-th piece)
+    uint32_t first;  // stream index of its first token
+};
 __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const uint32_t B_, const uint32_t end_bit_, uint32_t *rows_, const uint32_t xt_bits,
-                                             uint32_t &ntok_out, uint32_t &term_why, uint32_t &term_pos STAT_PARAM)
+                                             uint32_t &ntok_out, uint32_t &term_why, uint32_t &term_pos, PieceLane &pl STAT_PARAM)
 {
     const uint32_t lane = lane_id();
     const uint32_t B = rdfirst(B_), end_bit = rdfirst(end_bit_);
@@ -1189,6 +1202,10 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
     const uint32_t cnt = (fresh && e_nst > e_a0) ? e_nst - e_a0 : 0u;
     const uint32_t incl = wave_incl_scan(cnt);
     const uint64_t nonempty = __ballot(cnt != 0);
+    pl.node = node;
+    pl.e_a0 = e_a0;
+    pl.cnt = cnt;
+    pl.first = incl - cnt;
     WSYNC();  // the walk's LDS reads are done (the flush's state takes the window's place)
     if (cnt) {
         const uint32_t k = (uint32_t)__popcll(nonempty & lanemask_lt()), first = incl - cnt;
@@ -1206,12 +1223,109 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
     return (uint32_t)__popcll(nonempty);
 }
 
+
+// ---- tokens kernel only: a unit's token stream in the arena, its record -------------------------------------------------------
+// (see chip_internal.h for the record's layout; every member is wave-uniform)
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
+struct Emit {
+    uint32_t *arena = nullptr;  // token arena, `arena_words` long, handed out in pieces of PIPE_ARENA_WORDS through counters[1]
+    uint32_t arena_words = 0;
+    uint32_t *counters = nullptr;
+    uint32_t cur = 0, end = 0;  // the wave's piece of the arena: next free word, end (kept from unit to unit)
+    bool exhausted = false;     // the arena has run out: every further unit of this wave takes the one-kernel path
+    uint32_t *rec_base = nullptr;  // the records, PIPE_REC_WORDS per unit
+    uint32_t *rec = nullptr;    // the unit's record
+    uint32_t nseg = 0;
+    uint32_t ext_off = 0, ext_n = 0;  // the open run of tokens (ext_n == 0: none)
+    bool fail = false;          // the unit does not fit the record / the arena
+};
+
+__device__ __forceinline__ void emit_segment(Emit &E, uint32_t w0, uint32_t w1)
+{
+    if (E.nseg >= PIPE_MAXSEG) {
+        E.fail = true;
+        return;
+    }
+    if (lane_id() == 0) {
+        E.rec[8u + 2u * E.nseg] = w0;
+        E.rec[9u + 2u * E.nseg] = w1;
+    }
+    E.nseg++;
+}
+
+__device__ __forceinline__ void emit_close(Emit &E)
+{
+    if (E.ext_n) emit_segment(E, E.ext_off, E.ext_n);
+    E.ext_n = 0;
+}
+
+// The ntok tokens of a walk round's true stream, piece by piece (lane n copies the n-th piece from the row it lies in), appended
+// to the unit's token stream.  False: no room.
+__device__ CHIP_PHASE_FN bool emit_round(Emit &E, const uint32_t *rows_, const PieceLane &pl, const uint32_t ntok_)
+{
+    const uint32_t ntok = rdfirst(ntok_);
+    if (ntok == 0) return true;
+    if (E.exhausted || E.fail) {
+        E.fail = true;
+        return false;
+    }
+    if (E.cur + ntok > E.end) {  // (ntok <= 64 rows x ROW_TOKENS = a whole piece)
+        emit_close(E);
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&E.counters[1], PIPE_ARENA_WORDS);
+        base = rdfirst(base);
+        if (base > E.arena_words || E.arena_words - base < PIPE_ARENA_WORDS) {
+            E.exhausted = true;
+            E.fail = true;
+            return false;
+        }
+        E.cur = base;
+        E.end = base + PIPE_ARENA_WORDS;
+    }
+    if (E.ext_n == 0) E.ext_off = E.cur;
+    GAS uint32_t *const dst = (GAS uint32_t *)rdfirst_gptr(E.arena) + E.cur;
+    GAS const uint32_t *const row = (GAS const uint32_t *)rdfirst_gptr(rows_) + row_base(pl.node);
+    uint32_t k = pl.e_a0, d = pl.first;
+    const uint32_t endk = pl.e_a0 + pl.cnt;
+    // a row holds four tokens per 16 bytes (row_word): single tokens up to the first whole group, whole groups, single tokens
+#pragma unroll
+    for (int h = 0; h < 3; h++) {
+        if (k < endk && (k & 3u)) {
+            dst[d] = row[row_word(k)];
+            k++;
+            d++;
+        }
+    }
+    while (__any(k + 4u <= endk)) {
+        if (k + 4u <= endk) {
+            const u32x4 v = *(GAS const u32x4 *)(row + 8u * k);  // row_word(k) = 8 k for k = 0 mod 4
+            *(GAS u32x4_a4 *)(dst + d) = v;
+            k += 4u;
+            d += 4u;
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < 3; h++) {
+        if (k < endk) {
+            dst[d] = row[row_word(k)];
+            k++;
+            d++;
+        }
+    }
+    E.cur += ntok;
+    E.ext_n += ntok;
+    return true;
+}
+
 // ---- a block's tokens: super-rounds of walk, path resolve, execution ------------------------------------
 // Decode the tokens of one deflate block from bit `pos` on (tables are in LDS), executing them into gout.  On return `pos` is
 // behind the end-of-block code (status stays ST_RUNNING) or status holds the reason decoding stopped.
+// PIPE (tokens kernel): the true stream is not executed but appended to the unit's token stream (E); a unit that does not fit
+// leaves with status CHIP_NEED_OUTPUT and E.fail set.
+template <bool PIPE>
 __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, const uint32_t end_bit, uint8_t *gout, uint32_t &opos,
                                            const uint32_t cap, int32_t &status, uint32_t *rows, const uint32_t xt_bits, const uint32_t eob_len,
-                                           const uint32_t flags STAT_PARAM)
+                                           const uint32_t flags, Emit &E STAT_PARAM)
 {
     pos = rdfirst(pos);
     opos = rdfirst(opos);
@@ -1222,17 +1336,30 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
         }
         STAT_T0();
         uint32_t ntok = 0, why = 0, tpos = 0;
-        const uint32_t npk = walk_round(L, w, pos, end_bit, rows, xt_bits, ntok, why, tpos STAT_ARG);
+        PieceLane pl;
+        const uint32_t npk = walk_round(L, w, pos, end_bit, rows, xt_bits, ntok, why, tpos, pl STAT_ARG);
         int32_t st2 = ST_RUNNING;
         bool flushed = true;
         uint32_t ovf[3] = {0, 0, 0};
-        if (npk) flushed = flush_tokens(L, rows, ntok, npk, gout, opos, cap, st2, ovf STAT_ARG);
+        if constexpr (PIPE) {
+            if (npk && !emit_round(E, rows, pl, ntok)) {
+                flushed = false;
+                st2 = CHIP_NEED_OUTPUT;
+            }
+        } else {
+#ifdef CHIP_EXP_NO_FLUSH  // ablation (no output): the walk alone -- header, tables, walk, path resolve, token rows
+            asm volatile("" ::"s"(npk), "s"(ntok));
+#else
+            if (npk) flushed = flush_tokens(L, rows, ntok, npk, gout, opos, cap, st2, ovf STAT_ARG);
+#endif
+        }
         w.win0 = 0xffffffffu;  // the phases used the header window's place
         STAT_ACC(20);
         if (!flushed) {
             status = st2;
             // CHIP_F_COMPU_STATUS: zlib's position when the output filled (else the position stays at the round's start)
-            if ((flags & F_COMPU_STATUS) && st2 == CHIP_NEED_OUTPUT) pos = overflow_bit(L, w, rows, ntok, npk, ovf[0], ovf[1], ovf[2], pos);
+            if constexpr (!PIPE)
+                if ((flags & F_COMPU_STATUS) && st2 == CHIP_NEED_OUTPUT) pos = overflow_bit(L, w, rows, ntok, npk, ovf[0], ovf[1], ovf[2], pos);
             return;
         }
         if (why == R_NEED_INPUT) {
@@ -1255,14 +1382,23 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
 #define CHIP_WAVES_PER_SIMD 4
 #endif
 // one unit, start to finish, by the calling wave; scratch = the wave's token rows in HBM
-__device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, uint32_t *scratch)
+// PIPE (tokens kernel): nothing is executed and no result is written -- the unit's tokens and stored runs go to its record (E); a
+// unit that does not reach the end of its stream, or does not fit, is put on the fallback list for inflate_kernel.
+template <bool PIPE>
+__device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, const uint32_t u, WaveLds &L, uint32_t *scratch, Emit &E, uint32_t *fallback)
 {
     const uint32_t lane = lane_id();
 
     const uint8_t *gin = a.in_base + a.in_off[u];
     const uint32_t in_len = a.in_len[u];
-    uint8_t *gout = a.out_base + a.out_off[u];
-    const uint32_t cap = a.out_cap[u];
+    uint8_t *gout = PIPE ? nullptr : a.out_base + a.out_off[u];
+    const uint32_t cap = PIPE ? 0xffffffffu : a.out_cap[u];
+    if constexpr (PIPE) {
+        E.rec = rdfirst_ptr(E.rec_base + (size_t)u * PIPE_REC_WORDS);
+        E.nseg = 0;
+        E.ext_n = 0;
+        E.fail = false;
+    }
 
     InWin w;
     const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);
@@ -1286,7 +1422,7 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
     uint32_t ck_bit = 0, ck_opos = 0;  // last block boundary reached (streaming decoder: where the next call resumes)
     bool resumed = false;
     uint32_t run_check = 0, run_cov = 0, out_dropped = 0;  // running trailer check: value, stream bytes covered; bytes dropped in front
-    if (a.resume) {
+    if (!PIPE && a.resume) {
         const uint32_t *rs = a.resume + RESUME_WORDS * u;
         const uint32_t r0 = rs[0], r1 = rs[1], r2 = rs[2];
         if (r0 != 0 && r0 <= in_len * 8u && r1 <= cap) {
@@ -1347,8 +1483,15 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
             uint32_t room = cap - opos;
             uint32_t ncopy = blen < avail ? blen : avail;
             if (ncopy > room) ncopy = room;
-            wave_copy_stored(gout + opos, w.g32, w.total_dw, pos >> 3, ncopy);
-            opos += ncopy;
+            if constexpr (PIPE) {
+                if (ncopy == blen && blen) {  // a stored run of the record (a short one goes the one-kernel way: status below)
+                    emit_close(E);
+                    emit_segment(E, (pos >> 3) - mis, blen | PIPE_SEG_STORED);
+                }
+            } else {
+                wave_copy_stored(gout + opos, w.g32, w.total_dw, pos >> 3, ncopy);
+                opos += ncopy;
+            }
             pos += ncopy * 8u;
             if (ncopy < blen) {
                 // zlib reports Z_OK here; compu calls it NeedInput when no input is left (mod.rs:476-479)
@@ -1475,12 +1618,43 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
         }
         STAT_ACC(0);
         __builtin_amdgcn_s_setprio(0);
-        decode_block(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len, a.flags STAT_ARG);
+        decode_block<PIPE>(L, w, pos, end_bit, gout, opos, cap, status, scratch, tables == 1 ? XT_BITS_FIXED : XT_BITS, eob_len, a.flags, E STAT_ARG);
         __builtin_amdgcn_s_setprio(2);  // block headers and table builds are short dependent chains: ahead of the other waves' bulk work
         STAT_T0();
     }
     __builtin_amdgcn_s_setprio(0);
     STAT_ACC(0);
+    if constexpr (PIPE) {
+        // The record is complete when the stream ended at its last block and the trailer is there; the trailer's values are
+        // checked by lz77_kernel, which has the bytes.  Everything else is inflate_kernel's: it reports what zlib would.
+        uint32_t want = 0, isize = 0;
+        uint32_t k = (pos - start_bit + 7u) >> 3;
+        bool done = status == CHIP_FINISHED && !E.fail;
+        if (done && wrap == 1) {
+            if (in_len - k < 4) done = false;
+            else want = ((uint32_t)gin[k] << 24) | ((uint32_t)gin[k + 1] << 16) | ((uint32_t)gin[k + 2] << 8) | gin[k + 3];
+            k += 4;
+        } else if (done && wrap == 2) {
+            if (in_len - k < 8) done = false;
+            else {
+                want = gin[k] | ((uint32_t)gin[k + 1] << 8) | ((uint32_t)gin[k + 2] << 16) | ((uint32_t)gin[k + 3] << 24);
+                isize = gin[k + 4] | ((uint32_t)gin[k + 5] << 8) | ((uint32_t)gin[k + 6] << 16) | ((uint32_t)gin[k + 7] << 24);
+            }
+            k += 8;
+        }
+        if (done) emit_close(E);
+        done = done && !E.fail;
+        if (lane == 0) {
+            E.rec[0] = done ? PIPE_ST_TOKENS : PIPE_ST_FALLBACK;
+            E.rec[1] = E.nseg;
+            E.rec[2] = wrap;
+            E.rec[3] = rdfirst(want);
+            E.rec[4] = rdfirst(isize);
+            E.rec[5] = k < in_len ? k : in_len;
+            if (!done) fallback[atomicAdd(&E.counters[2], 1u)] = u;
+        }
+        return;
+    }
     if (status == CHIP_FINISHED && wrap) {
         // trailer: gzip CRC-32 + ISIZE (little endian), zlib Adler-32 (big endian)
         uint32_t k = (pos - start_bit + 7u) >> 3;
@@ -1553,13 +1727,37 @@ __global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void inflate_kernel(BatchA
     __shared__ WaveLds L;
     uint32_t *grow = scratch + (size_t)blockIdx.x * SCRATCH_WORDS;
     const uint32_t limit = a.sel_n ? *a.sel_n : a.n;
+    Emit none;
     for (;;) {
         uint32_t i = 0;
         if (lane_id() == 0) i = atomicAdd(next_unit, 1u);
         i = rdfirst(i);
         if (i >= limit) break;
         const uint32_t u = a.sel ? rdfirst(a.sel[i]) : i;
-        inflate_unit(a, u, L, grow);
+        inflate_unit<false>(a, u, L, grow, none, nullptr);
+        WSYNC();  // the next unit reuses the LDS
+    }
+}
+
+// First kernel of the pipeline (chip_internal.h): the same persistent grid, but a unit's tokens go to the arena instead of being
+// executed; lz77_kernel follows on the stream, then inflate_kernel over the fallback list.
+__global__ __launch_bounds__(64, CHIP_WAVES_PER_SIMD) void tokens_kernel(BatchArgs a, uint32_t *scratch, PipeScratch p)
+{
+    __shared__ WaveLds L;
+    uint32_t *grow = scratch + (size_t)blockIdx.x * SCRATCH_WORDS;
+    const uint32_t limit = a.sel_n ? *a.sel_n : a.n;
+    Emit E;
+    E.arena = p.arena;
+    E.arena_words = p.arena_words;
+    E.counters = p.counters;
+    E.rec_base = p.rec;
+    for (;;) {
+        uint32_t i = 0;
+        if (lane_id() == 0) i = atomicAdd(&p.counters[0], 1u);
+        i = rdfirst(i);
+        if (i >= limit) break;
+        const uint32_t u = a.sel ? rdfirst(a.sel[i]) : i;
+        inflate_unit<true>(a, u, L, grow, E, p.fallback);
         WSYNC();  // the next unit reuses the LDS
     }
 }
@@ -1573,6 +1771,10 @@ struct LaunchSlot {
     int blocks = 0;
     uint32_t *route = nullptr;  // routed batches: [0,1] list lengths, then two index lists of route_cap entries
     size_t route_cap = 0;
+    // the two-kernel pipeline's scratch, sized by the largest batch launched here: unit records, fallback list, counters, token arena
+    uint32_t *pipe_rec = nullptr, *pipe_fb = nullptr, *pipe_arena = nullptr;
+    size_t pipe_units = 0, pipe_arena_words = 0;
+    bool pipe_off = false;  // the arena could not be allocated: this slot stays with the one-kernel path
 };
 std::mutex g_slot_mu;
 std::map<std::pair<int, hipStream_t>, LaunchSlot> g_slots;
@@ -1614,6 +1816,52 @@ hipError_t slot_for(hipStream_t stream, uint32_t n, LaunchSlot &out)
 }
 }  // namespace
 
+namespace {
+// Pipeline scratch of the slot for a batch of n units (caller holds g_slot_mu).  The arena gets 32 Ki tokens (128 KB) per unit of the
+// largest batch -- twice a 64 KiB unit's output, a 64 KiB unit of this class has 20-30 Ki tokens -- within a sixth of the device's
+// memory; tokens_kernel sends the units that find no room to the one-kernel path.  False: not available, use the one-kernel path.
+bool pipe_scratch(LaunchSlot &sl, hipStream_t stream, uint32_t n)
+{
+    if (sl.pipe_off) return false;
+    if (n <= sl.pipe_units) return true;
+    if (sl.pipe_rec && hipStreamSynchronize(stream) != hipSuccess) return false;  // launches on the stream still use it
+    (void)hipFree(sl.pipe_rec);
+    (void)hipFree(sl.pipe_arena);
+    sl.pipe_rec = sl.pipe_fb = sl.pipe_arena = nullptr;
+    sl.pipe_units = sl.pipe_arena_words = 0;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return false;
+    const size_t units = (size_t)n + n / 4 + 16;
+    size_t words = units * 32768;
+    const size_t cap_words = (total_b / 6 < free_b / 2 ? total_b / 6 : free_b / 2) / 4;
+    if (words > cap_words) words = cap_words;
+    if (words > 0xffff0000ull) words = 0xffff0000ull;
+    if (words < 4 * (size_t)PIPE_ARENA_WORDS) return false;
+    uint32_t *rec = nullptr, *arena = nullptr;
+    if (hipMalloc((void **)&rec, (units * (PIPE_REC_WORDS + 1) + 16) * 4) != hipSuccess) return false;
+    if (hipMalloc((void **)&arena, words * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipFree(rec);
+        sl.pipe_off = true;
+        return false;
+    }
+    sl.pipe_rec = rec + 16;  // counters first
+    sl.pipe_fb = rec + 16 + units * PIPE_REC_WORDS;
+    sl.pipe_arena = arena;
+    sl.pipe_units = units;
+    sl.pipe_arena_words = words;
+    return true;
+}
+bool pipe_enabled()
+{
+    static const bool on = [] {
+        const char *e = getenv("CHIP_INFLATE_PIPE");  // 1: batches take the two-kernel pipeline (work in progress: not yet the faster path)
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+}  // namespace
+
 hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts)
 {
     int dev = 0;
@@ -1648,6 +1896,8 @@ hipError_t release_inflate_scratch()
         if (it->first.first == dev) {
             (void)hipFree(it->second.scratch);
             (void)hipFree(it->second.route);
+            if (it->second.pipe_rec) (void)hipFree(it->second.pipe_rec - 16);
+            (void)hipFree(it->second.pipe_arena);
             it = g_slots.erase(it);
         } else {
             ++it;
@@ -1665,6 +1915,8 @@ void release_inflate_scratch_of(hipStream_t stream)
     if (it != g_slots.end()) {
         (void)hipFree(it->second.scratch);
         (void)hipFree(it->second.route);
+        if (it->second.pipe_rec) (void)hipFree(it->second.pipe_rec - 16);
+        (void)hipFree(it->second.pipe_arena);
         g_slots.erase(it);
     }
 }
@@ -1680,8 +1932,39 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
     LaunchSlot sl;
     hipError_t e = slot_for(stream, a.n, sl);
     if (e != hipSuccess) return e;
-    if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
     const uint32_t blocks = a.n < (uint32_t)sl.blocks ? a.n : (uint32_t)sl.blocks;
+    // A batch (not a streaming decoder's call, which carries its state in a.resume) takes the two-kernel pipeline: tokens_kernel,
+    // lz77_kernel, then inflate_kernel over the units those two have put on the fallback list (usually none).
+    if (!a.resume && pipe_enabled()) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        LaunchSlot &ref = g_slots[{dev, stream}];
+        if (pipe_scratch(ref, stream, a.n)) {
+            PipeScratch p;
+            p.rec = ref.pipe_rec;
+            p.arena = ref.pipe_arena;
+            p.arena_words = (uint32_t)ref.pipe_arena_words;
+            p.counters = ref.pipe_rec - 16;
+            p.fallback = ref.pipe_fb;
+            if ((e = hipMemsetAsync(p.counters, 0, 16, stream)) != hipSuccess) return e;
+            hipLaunchKernelGGL(tokens_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, p);
+            if ((e = hipGetLastError()) != hipSuccess) return e;
+            if ((e = launch_lz77(a, p, stream)) != hipSuccess) return e;
+            BatchArgs fb = a;
+            fb.sel = p.fallback;
+            fb.sel_n = p.counters + 2;
+            hipLaunchKernelGGL(inflate_kernel, dim3(blocks), dim3(64), 0, stream, fb, sl.scratch, p.counters + 3);
+            e = hipGetLastError();
+            static const bool dbg = getenv("CHIP_PIPE_DEBUG") != nullptr;  // diagnostic: waits for the launches and prints the counters
+            if (dbg && e == hipSuccess && hipStreamSynchronize(stream) == hipSuccess) {
+                uint32_t c[4] = {0, 0, 0, 0};
+                (void)hipMemcpy(c, p.counters, 16, hipMemcpyDeviceToHost);
+                fprintf(stderr, "[chip pipe] units %u: taken %u, arena words %u of %u, fallback %u\n", a.n, c[0], c[1], p.arena_words, c[2]);
+            }
+            return e;
+        }
+    }
+    if ((e = hipMemsetAsync(sl.counter, 0, 4, stream)) != hipSuccess) return e;
     hipLaunchKernelGGL(inflate_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
     return hipGetLastError();
 }

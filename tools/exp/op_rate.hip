@@ -27,7 +27,21 @@
 #define ADPP asm volatile("v_add_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %1, %1, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %2, %2, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %3, %3, %4 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %4, %4, %5 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %5, %5, %6 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %6, %6, %7 row_shr:1 row_mask:0xf bank_mask:0xf\n\tv_add_u32_dpp %7, %7, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
 #define AMAD asm volatile("v_mad_u64_u32 %0, vcc, %8, %9, %0\n\tv_mad_u64_u32 %1, vcc, %8, %9, %1\n\tv_mad_u64_u32 %2, vcc, %8, %9, %2\n\tv_mad_u64_u32 %3, vcc, %8, %9, %3\n\tv_mad_u64_u32 %4, vcc, %8, %9, %4\n\tv_mad_u64_u32 %5, vcc, %8, %9, %5\n\tv_mad_u64_u32 %6, vcc, %8, %9, %6\n\tv_mad_u64_u32 %7, vcc, %8, %9, %7" : "+v"(q0), "+v"(q1), "+v"(q2), "+v"(q3), "+v"(q4), "+v"(q5), "+v"(q6), "+v"(q7) : "v"(s), "v"(r0) : "vcc");
 
+#define ALIT(op) asm volatile(op " %0, 0x9e3779b9, %0\n\t" op " %1, 0x9e3779b9, %1\n\t" op " %2, 0x9e3779b9, %2\n\t" op " %3, 0x9e3779b9, %3\n\t" op " %4, 0x9e3779b9, %4\n\t" op " %5, 0x9e3779b9, %5\n\t" op " %6, 0x9e3779b9, %6\n\t" op " %7, 0x9e3779b9, %7" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
+#define AIMM(op) asm volatile(op " %0, %0, 5, 9\n\t" op " %1, %1, 5, 9\n\t" op " %2, %2, 5, 9\n\t" op " %3, %3, 5, 9\n\t" op " %4, %4, 5, 9\n\t" op " %5, %5, 5, 9\n\t" op " %6, %6, 5, 9\n\t" op " %7, %7, 5, 9" : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7));
 BODY(k_add, A1("v_add_u32"))
+BODY(k_add64e, A1("v_add_u32_e64"))
+BODY(k_and32, A1("v_and_b32"))
+BODY(k_and64e, A1("v_and_b32_e64"))
+BODY(k_xor32, A1("v_xor_b32"))
+BODY(k_lshr32, A1("v_lshrrev_b32"))
+BODY(k_addlit, ALIT("v_add_u32"))
+BODY(k_bfeimm, AIMM("v_bfe_u32"))
+BODY(k_sub, A1("v_sub_u32"))
+BODY(k_min, A1("v_min_u32"))
+BODY(k_addf, A1("v_add_f32"))
+BODY(k_and_or, A3("v_and_or_b32"))
+BODY(k_lshl_or, A3("v_lshl_or_b32"))
 BODY(k_lshl, A1("v_lshlrev_b32"))
 BODY(k_mul, A1("v_mul_lo_u32"))
 BODY(k_mulhi, A1("v_mul_hi_u32"))
@@ -70,6 +84,18 @@ void run(const char *name, K kern, int per_iter)
 int main()
 {
     run("v_add_u32", k_add, 8);
+    run("v_add_u32_e64", k_add64e, 8);
+    run("v_and_b32 (e32)", k_and32, 8);
+    run("v_and_b32_e64", k_and64e, 8);
+    run("v_xor_b32 (e32)", k_xor32, 8);
+    run("v_lshrrev_b32 (e32)", k_lshr32, 8);
+    run("v_sub_u32", k_sub, 8);
+    run("v_min_u32", k_min, 8);
+    run("v_add_f32", k_addf, 8);
+    run("v_add_u32 + literal", k_addlit, 8);
+    run("v_bfe_u32 imm", k_bfeimm, 8);
+    run("v_and_or_b32", k_and_or, 8);
+    run("v_lshl_or_b32", k_lshl_or, 8);
     run("v_lshlrev_b32", k_lshl, 8);
     run("v_mul_lo_u32", k_mul, 8);
     run("v_mul_hi_u32", k_mulhi, 8);

@@ -6,7 +6,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(path)):
     acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, cs in acc.items():
-    if "inflate" not in k and "zstd" not in k and "deflate" not in k:
+    if not any(t in k for t in ("inflate", "zstd", "deflate", "tokens_kernel", "lz77")):
         continue
     print(k[:60])
     for c, v in sorted(cs.items()):
