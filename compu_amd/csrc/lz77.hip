@@ -42,8 +42,12 @@ constexpr uint32_t X_BLK = 256;       // tokens per block
 constexpr uint32_t X_SBLK = 4096;     // stored bytes per block
 constexpr uint32_t X_MAXBLK = 336;    // blocks per unit: 65536 tokens / 256, 65536 stored bytes / 4096, one partial block per segment
 constexpr uint32_t X_POOL = 128;      // waiting matches per wave
+#ifndef CHIP_X_PASS_AT
+#define CHIP_X_PASS_AT 40
+#endif
+constexpr uint32_t X_PASS_AT = CHIP_X_PASS_AT;  // a pass over the pool when it holds this many (<= X_POOL - 64: a group may add 64)
 constexpr uint32_t X_NOTYET = 0xffffffffu;
-constexpr uint32_t X_COPY_MAX = 32;   // bytes a lane copies for its match; longer (and self-overlapping) matches are copied by the whole wave
+constexpr uint32_t X_COPY_MAX = 31;   // bytes a lane copies for its match (16 + 8 + 4 + 2 + 1); longer (and self-overlapping) matches are copied by the whole wave
 constexpr uint32_t X_BMW = PIPE_IMAGE_BYTES / 32;
 
 struct __attribute__((packed)) U32u { uint32_t v; };
@@ -58,11 +62,12 @@ struct alignas(16) XLds {
     uint32_t bm[X_BMW + 12];              // bit b of word w: image byte 32 w + b is final; at the end: CRC tables
     uint32_t pa[X_NW][X_POOL];            // per wave, waiting match: first output offset | distance << 16 ...
     uint16_t pl[X_NW][X_POOL];            // ... and its length
-    uint32_t blk_start[X_MAXBLK + 2];     // [b] output offset of block b's first byte (X_NOTYET until block b - 1 knows its length)
+    uint32_t blk_len[X_MAXBLK + 8];       // [8 + b] output bytes of block b (X_NOTYET until its wave has added them up); [0..7] = 0
+    uint32_t total;                       // the unit's output bytes (set by the last block's wave)
     uint32_t seg[2 * PIPE_MAXSEG];
     uint32_t part[2 * X_NW];
     uint32_t bad;
-    uint32_t trash[64];                   // lane l's word for the stores it must not make (see the kernel)
+    uint32_t trash[64 + 4];               // lane l's word for the stores it must not make (see the kernel)
 };
 static_assert(sizeof(XLds) <= 80 * 1024, "two workgroups per CU");
 static_assert(sizeof(((XLds *)0)->bm) >= 2048 * 4, "the CRC tables take the bit map's place");
@@ -252,7 +257,8 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
     const uint32_t *const rec = p.rec + (size_t)u * PIPE_REC_WORDS;
     if (rec[0] != PIPE_ST_TOKENS) return;  // the unit is on the fallback list already
     const uint32_t nseg = rdfirst(rec[1]);
-    for (uint32_t k = tid; k < X_MAXBLK + 2; k += X_THREADS) L.blk_start[k] = k == 0 ? 0u : X_NOTYET;
+    for (uint32_t k = tid; k < X_MAXBLK + 8; k += X_THREADS) L.blk_len[k] = k < 8 ? 0u : X_NOTYET;
+    if (tid == 0) L.total = nseg ? X_NOTYET : 0u;
     for (uint32_t k = tid; k < X_BMW + 12; k += X_THREADS) L.bm[k] = 0;
     if (tid < 2 * nseg) L.seg[tid] = rec[8 + tid];
     if (tid == 0) L.bad = 0;
@@ -268,8 +274,8 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
         lds_u8 *const img = (lds_u8 *)L.img;
         const uint32_t img_a = (uint32_t)(uintptr_t)img;  // LDS byte addresses: a store that a lane must not make goes to the lane's trash word
         const uint32_t bm_a = (uint32_t)(uintptr_t)(LDS_AS uint32_t *)L.bm;
-        const uint32_t pa_a = (uint32_t)(uintptr_t)(LDS_AS uint32_t *)L.pa[wave];
-        const uint32_t pl_a = (uint32_t)(uintptr_t)(LDS_AS uint16_t *)L.pl[wave];
+        LDS_AS uint32_t *const pa = (LDS_AS uint32_t *)L.pa[wave];
+        LDS_AS uint16_t *const pl = (LDS_AS uint16_t *)L.pl[wave];
         const uint32_t trash_a = (uint32_t)(uintptr_t)(LDS_AS uint32_t *)L.trash + 4u * lane;
         uint32_t np = 0;  // waiting matches of this wave
         // this wave's blocks: segment s, block j of it, number gb among the unit's blocks
@@ -283,12 +289,12 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
             while (it_s < nseg) {
                 const uint32_t off = rdfirst(L.seg[2 * it_s]), cw = rdfirst(L.seg[2 * it_s + 1]), cnt = cw & ~PIPE_SEG_STORED;
                 const uint32_t st = cw >> 31;
-                const uint32_t per = st ? X_SBLK : X_BLK, nb = (cnt + per - 1) / per;
+                const uint32_t sh = st ? 12u : 8u, per = 1u << sh, nb = (cnt + per - 1u) >> sh;  // (X_SBLK = 2^12, X_BLK = 2^8)
                 if (it_j < nb) {
                     b.valid = 1;
                     b.stored = st;
-                    b.src = off + per * it_j;
-                    b.n = cnt - per * it_j < per ? cnt - per * it_j : per;
+                    b.src = off + (it_j << sh);
+                    b.n = cnt - (it_j << sh) < per ? cnt - (it_j << sh) : per;
                     b.gb = it_gb0 + it_j;
                     it_j += X_NW;
                     return b;
@@ -341,7 +347,7 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
 #endif
         uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;  // the groups' first offsets inside the block
         uint32_t run = 0, B0 = 0, g = 0, passno = 0;
-        uint32_t placed = 0, scanned = 0;
+        uint32_t placed = 0, scanned = 0, lenpub = 0, lastB0 = 0;
         // One loop, one step per trip: the wave either takes the next step of its current block (place the block, then its four groups
         // of 64 tokens) or, when it cannot (the block's first offset is not known yet, the pool is full, nothing is left but the pool),
         // makes a pass over the pool.  (One copy of each piece of code: the kernel stays small; stores that a lane must not make go to its
@@ -362,12 +368,30 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
                 }
                 if (cur.stored) run = cur.n;
                 scanned = 1;
-                B0 = rdfirst(lds_peek(&L.blk_start[cur.gb]));
-                if (B0 == X_NOTYET) {
+                if (!lenpub) {
+                    // the block's length goes out at once: the waves behind place themselves by adding up the lengths in front of
+                    // them, none waits for another's place
+                    if (lane == 0) {
+                        lds_poke(&L.blk_len[8u + cur.gb], run);
+                    }
+                    lenpub = 1;
+                }
+                // first offset = this wave's last block's first offset + the lengths of the eight blocks since (its own and the other
+                // waves' seven; the array starts with eight zeros for the unit's first blocks)
+                uint32_t l0, l1, l2, l3, l4, l5, l6, l7;
+                u32x2 l01, l23, l45, l67;
+                asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %4 offset0:2 offset1:3\n\tds_read2_b32 %2, %4 offset0:4 offset1:5\n\tds_read2_b32 %3, %4 offset0:6 offset1:7\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(l01), "=&v"(l23), "=&v"(l45), "=&v"(l67)
+                             : "v"((uint32_t)(uintptr_t)(LDS_AS uint32_t *)&L.blk_len[cur.gb])
+                             : "memory");
+                l0 = rdfirst(l01.x), l1 = rdfirst(l01.y), l2 = rdfirst(l23.x), l3 = rdfirst(l23.y), l4 = rdfirst(l45.x), l5 = rdfirst(l45.y), l6 = rdfirst(l67.x), l7 = rdfirst(l67.y);
+                if ((l0 | l1 | l2 | l3 | l4 | l5 | l6 | l7) >> 31) {  // (a length is below 2^31; X_NOTYET is all ones)
                     blocked = 1;
                     XSTAT_ADD(4, 1);
                 } else {
-                    if (lane == 0) lds_poke(&L.blk_start[cur.gb + 1u], B0 + run);  // the next block may place itself
+                    B0 = lastB0 + l0 + l1 + l2 + l3 + l4 + l5 + l6 + l7;
+                    lastB0 = B0;
+                    if (cur.gb + 1u == nblk && lane == 0) lds_poke(&L.total, B0 + run);
                     if (B0 + run > PIPE_IMAGE_BYTES) {
                         if (lane == 0) atomicOr(&L.bad, 1u);
                         break;
@@ -393,78 +417,79 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
                     }
                 }
             }
-            if (!blocked && cur.valid && g < 4u && 64u * g < cur.n && np > X_POOL - 64u) blocked = 1;  // no room for 64 more matches
+            // A pass as soon as the pool holds most of a wave's worth: what waits in a pool is not final, and other waves' matches wait for it
+            // (with eight waves each holding a full pool most of the last 8 KB of output would be waiting).
+            if (!blocked && cur.valid && g < 4u && 64u * g < cur.n && np >= X_PASS_AT) blocked = 1;
             XSTAT_T(8);
             if (blocked) {
                 // ---- one pass over the pool's oldest 64 entries, one per lane: the matches whose source bytes are final are copied, the
-                // others go to the back of the queue.  A lane copies up to 16 bytes; every fourth pass up to 32.
+                // others go to the back of the queue.  A lane copies up to 15 bytes; every fourth pass up to 31.
                 uint32_t progress = 0;
                 if (np) {
-                    const uint32_t n = np < 64u ? np : 64u;
-                    const uint32_t tier = (passno & 3u) ? 16u : X_COPY_MAX;
+                    const uint32_t n = np < 64u ? np : 64u, rest = np - n;
+                    const bool wide = (passno & 3u) == 0;
                     passno++;
-                    const bool act = lane < n;
-                    uint32_t ea, el, ta, tl;
-                    asm volatile("ds_read_b32 %0, %4\n\tds_read_u16 %1, %5\n\tds_read_b32 %2, %4 offset:256\n\tds_read_u16 %3, %5 offset:128\n\ts_waitcnt lgkmcnt(0)"
-                                 : "=&v"(ea), "=&v"(el), "=&v"(ta), "=&v"(tl)
-                                 : "v"(pa_a + 4u * lane), "v"(pl_a + 2u * lane)
-                                 : "memory");
-                    ea = act ? ea : 0u;
-                    const uint32_t len = act ? el : 0u;
+                    uint32_t ea = 0, len = 0;
+                    if (lane < n) {
+                        ea = pa[lane];
+                        len = pl[lane];
+                    }
+                    uint32_t ta = 0, tl = 0;
+                    if (lane < rest) {
+                        ta = pa[64u + lane];
+                        tl = pl[64u + lane];
+                    }
                     const uint32_t x = ea & 0xffffu, dist = ea >> 16;
                     const uint32_t src = x - dist;
-                    const bool simple = dist >= len;  // (not self-overlapping)
                     // the bits of [src, src + len) (at most 32 of them, in two words)
                     uint32_t w0, w1;
                     lds_peek2(&L.bm[src >> 5], w0, w1);
                     const uint32_t v = (uint32_t)((((uint64_t)w1 << 32) | w0) >> (src & 31u));
-                    const uint32_t needm = len >= 32u ? 0xffffffffu : (1u << len) - 1u;
-                    const bool rdy = len != 0 && len <= tier && simple && (~v & needm) == 0u;
-                    const uint32_t sa = img_a + src, da = img_a + x;
-                    uint32_t nb = rdy ? len : 0u;  // bytes this lane copies
-                    if (tier > 16u) {  // (uniform) whole first 16 bytes of the longer matches
-                        const bool big = nb > 16u;
+                    const uint32_t needm = (1u << (len & 31u)) - 1u;
+                    const bool rdy = len != 0 && len <= (wide ? X_COPY_MAX : 15u) && dist >= len && (~v & needm) == 0u;
+                    if (rdy) {
+                        // exactly len bytes: 16 (wide passes), 8, 4, 2, 1 as the bits of len say; a store that is not due goes to the lane's
+                        // trash word (a choice of address instead of a branch: exec-mask bookkeeping is scalar work, and there is a lot of it)
+                        uint32_t sa = img_a + src, da = img_a + x;
+                        if (wide) {
+                            uint32_t v0, v1, v2, v3;
+                            asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
+                                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                                         : "v"(sa)
+                                         : "memory");
+                            const bool big = (len & 16u) != 0;
+                            const uint32_t d0 = big ? da : trash_a;
+                            asm volatile("ds_write_b32 %0, %1\n\tds_write_b32 %0, %2 offset:4\n\tds_write_b32 %0, %3 offset:8\n\tds_write_b32 %0, %4 offset:12" ::"v"(d0), "v"(v0), "v"(v1),
+                                         "v"(v2), "v"(v3)
+                                         : "memory");
+                            sa += len & 16u;
+                            da += len & 16u;
+                        }
                         uint32_t v0, v1, v2, v3;
                         asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
                                      : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
                                      : "v"(sa)
                                      : "memory");
-                        const uint32_t d0 = big ? da : trash_a, d1 = big ? da + 4u : trash_a, d2 = big ? da + 8u : trash_a, d3 = big ? da + 12u : trash_a;
-                        asm volatile("ds_write_b32 %0, %4\n\tds_write_b32 %1, %5\n\tds_write_b32 %2, %6\n\tds_write_b32 %3, %7" ::"v"(d0), "v"(d1), "v"(d2), "v"(d3),
-                                     "v"(v0), "v"(v1), "v"(v2), "v"(v3)
+                        const uint32_t d8 = (len & 8u) ? da : trash_a;
+                        const uint32_t d4 = (len & 4u) ? da + (len & 8u) : trash_a;
+                        const uint32_t w4 = (len & 8u) ? v2 : v0;
+                        const uint32_t ww = (len & 8u) ? ((len & 4u) ? v3 : v2) : ((len & 4u) ? v1 : v0);  // the dword that holds bytes (len & 12) ..
+                        const uint32_t d2 = (len & 2u) ? da + (len & 12u) : trash_a;
+                        const uint32_t d1 = (len & 1u) ? da + (len & 14u) : trash_a;
+                        const uint32_t w1b = (len & 2u) ? ww >> 16 : ww;
+                        asm volatile("ds_write_b32 %0, %4\n\tds_write_b32 %0, %5 offset:4\n\tds_write_b32 %1, %6\n\tds_write_b16 %2, %7\n\tds_write_b8 %3, %8\n\ts_waitcnt lgkmcnt(0)" ::"v"(d8), "v"(d4),
+                                     "v"(d2), "v"(d1), "v"(v0), "v"(v1), "v"(w4), "v"(ww), "v"(w1b)
                                      : "memory");
-                        nb = big ? nb - 16u : nb;
-                    }
-                    {
-                        const uint32_t off = rdy && len > 16u ? 16u : 0u;
-                        const uint32_t s2a = sa + off, d2a = da + off;
-                        uint32_t v0, v1, v2, v3;
-                        asm volatile("ds_read_b32 %0, %4\n\tds_read_b32 %1, %4 offset:4\n\tds_read_b32 %2, %4 offset:8\n\tds_read_b32 %3, %4 offset:12\n\ts_waitcnt lgkmcnt(0)"
-                                     : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
-                                     : "v"(s2a)
-                                     : "memory");
-                        // exactly nb (0..16) bytes: whole dwords, then a half word, then a byte
-                        const uint32_t d0 = nb >= 4u ? d2a : trash_a, d1 = nb >= 8u ? d2a + 4u : trash_a, d2 = nb >= 12u ? d2a + 8u : trash_a, d3 = nb >= 16u ? d2a + 12u : trash_a;
-                        uint32_t w = nb < 4u ? v0 : nb < 8u ? v1 : nb < 12u ? v2 : v3;
-                        const uint32_t tb = d2a + (nb & 12u);
-                        const uint32_t dh = (nb & 2u) ? tb : trash_a;
-                        const uint32_t wb = (nb & 2u) ? w >> 16 : w;
-                        const uint32_t db = (nb & 1u) ? tb + (nb & 2u) : trash_a;
-                        asm volatile("ds_write_b32 %0, %6\n\tds_write_b32 %1, %7\n\tds_write_b32 %2, %8\n\tds_write_b32 %3, %9\n\tds_write_b16 %4, %10\n\tds_write_b8 %5, %11\n\ts_waitcnt lgkmcnt(0)" ::"v"(d0),
-                                     "v"(d1), "v"(d2), "v"(d3), "v"(dh), "v"(db), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(w), "v"(wb)
-                                     : "memory");
-                    }
-                    // (the bytes are in the image before their bits say so)
-                    {
-                        const uint64_t m = rdy ? (uint64_t)needm << (x & 31u) : 0ull;
+                        // (the bytes are in the image before their bits say so)
+                        const uint64_t m = (uint64_t)needm << (x & 31u);
                         const uint32_t wa = bm_a + 4u * (x >> 5);
-                        const uint32_t a0 = rdy ? wa : trash_a, a1 = (uint32_t)(m >> 32) ? wa + 4u : trash_a;
-                        asm volatile("ds_or_b32 %0, %2\n\tds_or_b32 %1, %3" ::"v"(a0), "v"(a1), "v"((uint32_t)m), "v"((uint32_t)(m >> 32)) : "memory");
+                        const uint32_t a1 = (uint32_t)(m >> 32) ? wa + 4u : trash_a;
+                        asm volatile("ds_or_b32 %0, %2\n\tds_or_b32 %1, %3" ::"v"(wa), "v"(a1), "v"((uint32_t)m), "v"((uint32_t)(m >> 32)) : "memory");
                     }
                     bool done = rdy;
                     // long (more than 32 bytes) and self-overlapping matches, one at a time by the whole wave (lanes 0..9 look at / set the
                     // words of a range of up to 258 bits)
-                    uint64_t cm = __ballot(len > X_COPY_MAX || (len != 0 && !simple));
+                    uint64_t cm = __ballot(len > X_COPY_MAX || dist < len);
                     while (cm) {
                         const uint32_t c = (uint32_t)__ffsll((long long)cm) - 1u;
                         cm &= cm - 1ull;
@@ -485,21 +510,24 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
                     // the queue moves up: what lay behind the 64 comes first, the entries that stay go behind it
                     const bool keep = len != 0 && !done;
                     const uint64_t km = __ballot(keep);
-                    const uint32_t r = (uint32_t)__popcll(km), rest = np - n;
-                    const uint32_t q = rest + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
-                    const bool mv = lane < rest;
-                    const uint32_t ma = mv ? pa_a + 4u * lane : trash_a, ml = mv ? pl_a + 2u * lane : trash_a;
-                    const uint32_t ka = keep ? pa_a + 4u * q : trash_a, kl = keep ? pl_a + 2u * q : trash_a;
-                    asm volatile("ds_write_b32 %0, %4\n\tds_write_b16 %1, %5\n\tds_write_b32 %2, %6\n\tds_write_b16 %3, %7\n\ts_waitcnt lgkmcnt(0)" ::"v"(ma), "v"(ml), "v"(ka),
-                                 "v"(kl), "v"(ta), "v"(tl), "v"(ea), "v"(el)
-                                 : "memory");
+                    const uint32_t r = (uint32_t)__popcll(km);
+                    if (lane < rest) {
+                        pa[lane] = ta;
+                        pl[lane] = (uint16_t)tl;
+                    }
+                    if (keep) {
+                        const uint32_t q = rest + __builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));
+                        pa[q] = ea;
+                        pl[q] = (uint16_t)len;
+                    }
+                    LSYNC();
                     np = rest + r;
                     progress = r < n;
                     XSTAT_ADD(0, 1);
                     XSTAT_ADD(1, progress ? 0 : 1);
                     XSTAT_ADD(2, __popcll(__ballot(rdy)));
                     XSTAT_ADD(11, n);
-                } else XSTAT_ADD(5, 1);
+                }
                 XSTAT_T(6);
                 if (!progress) {
                     // (the sources, or the block's place, are other waves' work)  A unit that cannot be finished here (L.bad: it takes the
@@ -516,7 +544,6 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
                 const uint32_t sg = g == 0 ? s0 : g == 1 ? s1 : g == 2 ? s2 : s3;
                 const bool valid = 64u * g + lane < cur.n;
                 const bool ismatch = valid && (tg & 512u) != 0;
-                const bool lit = valid && !ismatch;
                 const uint32_t x = B0 + sg;
                 const uint32_t len = tg & 0x1ffu, dist = __builtin_amdgcn_ubfe(tg, 10, 16) + 1u;
                 const bool far = ismatch && dist > x;  // "invalid distance too far back": the one-kernel path reports it
@@ -524,14 +551,15 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
                     if (lane == 0) atomicOr(&L.bad, 2u);
                 }
                 const uint64_t mm = __ballot(ismatch);
-                const uint32_t q = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, np));
-                const uint32_t la = lit ? img_a + x : trash_a;
-                const uint32_t qa = ismatch ? pa_a + 4u * q : trash_a, ql = ismatch ? pl_a + 2u * q : trash_a;
-                const uint32_t ba_ = lit ? bm_a + 4u * (x >> 5) : trash_a;
-                // (the literals are in the image before their bits say so)
-                asm volatile("ds_write_b8 %0, %4\n\tds_write_b32 %1, %5\n\tds_write_b16 %2, %6\n\ts_waitcnt lgkmcnt(0)\n\tds_or_b32 %3, %7" ::"v"(la), "v"(qa), "v"(ql), "v"(ba_),
-                             "v"(tg), "v"(x | (dist << 16)), "v"(len), "v"(1u << (x & 31u))
-                             : "memory");
+                if (ismatch) {
+                    const uint32_t q = __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, np));
+                    pa[q] = x | (dist << 16);
+                    pl[q] = (uint16_t)len;
+                }
+                if (valid && !ismatch) {
+                    // (the literal is in the image before its bit says so)
+                    asm volatile("ds_write_b8 %0, %2\n\ts_waitcnt lgkmcnt(0)\n\tds_or_b32 %1, %3" ::"v"(img_a + x), "v"(bm_a + 4u * (x >> 5)), "v"(tg), "v"(1u << (x & 31u)) : "memory");
+                }
                 np += (uint32_t)__popcll(mm);
                 g++;
                 XSTAT_T(7);
@@ -539,7 +567,9 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
             }
             // ---- the block is done: on to the wave's next one; its tokens were asked for three blocks ago (two sets may still be on
             // their way), the set it leaves is filled again
+            XSTAT_T(8);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            XSTAT_T(5);
             if (ph == 0) {
                 cur = ba;
                 X_TAKE("a0", "a1", "a2", "a3");
@@ -559,6 +589,7 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
             ph = ph == 2 ? 0 : ph + 1;
             placed = 0;
             scanned = 0;
+            lenpub = 0;
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (no token load is left in flight)
 #ifdef CHIP_STATS
@@ -569,7 +600,7 @@ __global__ __launch_bounds__(X_THREADS) void lz77_kernel(BatchArgs a, PipeScratc
     }
     __syncthreads();
     // ---- the whole stream is in the image: checks, then the stores
-    const uint32_t total = fits ? L.blk_start[nblk] : 0u;
+    const uint32_t total = fits ? L.total : 0u;
     const uint32_t cap = a.out_cap[u];
     bool ok = fits && L.bad == 0 && total != X_NOTYET && total <= PIPE_IMAGE_BYTES && total <= cap;
     const uint32_t wrap = rec[2];

@@ -1,4 +1,5 @@
 set -e
+export CHIP_INFLATE_PIPE=1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 timeout -k 5 60 python tools/time_run.py dynamic 256 2>&1 | grep -E "units"
 timeout -k 5 90 python tools/exp/pipe_dbg.py dynamic 8192 2 2>&1 | tail -3
@@ -13,5 +14,3 @@ for r in csv.DictReader(open(f)):
 PY
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU -d gpurun_out/r4_pmcA -o run --output-format csv -- python3 tools/prof_run.py dynamic 8192 3 > gpurun_out/r4_pmcA.log 2>&1
 python3 tools/pmc_summary.py gpurun_out/r4_pmcA/run_counter_collection.csv 8192 | grep -A8 lz77
-rocprofv3 --kernel-trace --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS -d gpurun_out/r4_pmcB -o run --output-format csv -- python3 tools/prof_run.py dynamic 8192 3 > gpurun_out/r4_pmcB.log 2>&1
-python3 tools/pmc_summary.py gpurun_out/r4_pmcB/run_counter_collection.csv 8192 | grep -A8 lz77

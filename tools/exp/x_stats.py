@@ -24,7 +24,7 @@ ol, iu, st = compu_amd.decode_batch(*args)
 torch.cuda.synchronize()
 assert (st == 2).all() and torch.equal(d_out, torch.from_numpy(pay).to(dev))
 s = stats.cpu().numpy().reshape(n, 24).astype(np.float64).mean(axis=0)
-names = ["pool passes", "passes without a copy", "matches by lanes", "matches by the wave", "trips: place unknown", "trips: blocked, pool empty", "cycles: passes", "cycles: groups",
+names = ["pool passes", "passes without a copy", "matches by lanes", "matches by the wave", "trips: place unknown", "cycles: waiting for tokens", "cycles: passes", "cycles: groups",
          "cycles: set-up", "cycles: asleep", "cycles: total (8 waves)", "entries looked at"]
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {s[i]:12.1f}")
