@@ -254,7 +254,7 @@ def _try_zlib_ng(parts, threads):
             "sample": f"first {m} units, zng_inflate through ctypes (the library releases no GIL by itself: ctypes does around each call)"}
 
 
-def cpu_baseline(packed, offs, lens, n_sample, threads, kind="dynamic", unit_kinds=None):
+def cpu_baseline(packed, offs, lens, n_sample, threads, kind="dynamic", unit_kinds=None, probes=True):
     """The oracle (CPU restatement of compu's decode loops) on a bounded sample; rank 0, N=1 only.  `mixed`: gzip units through the
     inflate oracle, zstd frames through the zstd oracle (unit_kinds[i] = 1 for gzip), timed together."""
     from oracle import oracle as O
@@ -290,6 +290,8 @@ def cpu_baseline(packed, offs, lens, n_sample, threads, kind="dynamic", unit_kin
         "kind": "port",
         "sample": f"first {n} units of the same batch ({n * UNIT / 2**20:.0f} MiB out), oracle/oracle_inflate.c, one decoder per thread reset per unit, output pre-touched, best of 3",
     }
+    if not probes:  # a side workload: the oracle's figure alone
+        return res
     m = min(n, 16384)
     parts = [bytes(packed[int(offs[i]) : int(offs[i]) + int(lens[i])]) for i in range(m)]
     # compu's real CPU backend, when the host has it (never the case in this image: stated either way)
@@ -319,6 +321,61 @@ def cpu_baseline(packed, offs, lens, n_sample, threads, kind="dynamic", unit_kin
                               "sample": f"first {m} units through Python's zlib.decompressobj(-15) (GIL released inside inflate)"}
     except Exception as e:  # the figure is optional
         res["system_zlib"] = {"error": str(e)}
+    return res
+
+
+def cpu_baseline_encode(payload, n_sample, threads, level=1):
+    """configs[3] on the host: compu's encode loop (src/encoder/zlib_ng.rs:50-104: one deflate stream per worker, reset per unit, level via
+    src/encoder/zlib_common.rs:47-66) with the host's system zlib at the same level, raw deflate, and the oracle's encoder
+    (oracle/oracle_deflate.c, the algorithm the GPU runs) on a quarter of that sample.  Input GB/s."""
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    from oracle import oracle as O
+
+    n = min(n_sample, len(payload) // UNIT)
+    mv = memoryview(payload)
+    res = {"unit": "GB/s (input)", "cores": threads, "kind": "port"}
+
+    def work_zlib(rng):
+        tot = 0
+        for i in rng:
+            co = zlib.compressobj(level, zlib.DEFLATED, -15)  # (Python's zlib has no deflateReset: a fresh stream per unit, allocation included)
+            tot += len(co.compress(mv[i * UNIT : (i + 1) * UNIT])) + len(co.flush())
+        return tot
+
+    chunks = [range(k, n, threads) for k in range(threads)]
+    with ThreadPoolExecutor(threads) as ex:
+        list(ex.map(work_zlib, [range(k, min(n, 4 * threads), threads) for k in range(threads)]))  # warm
+        t0 = time.perf_counter()
+        comp = sum(ex.map(work_zlib, chunks))
+        dt = time.perf_counter() - t0
+    res["system_zlib"] = {"value": round(n * UNIT / dt / 1e9, 3), "unit": "GB/s (input)", "threads": threads, "version": zlib.ZLIB_RUNTIME_VERSION,
+                          "ratio": round(comp / (n * UNIT), 4), "sample": f"first {n} units, zlib.compressobj({level}, DEFLATED, -15) per unit (GIL released inside deflate)"}
+    m = max(threads, n // 4)
+    O.lib()
+
+    def work_oracle(rng):
+        enc = O.DeflateEncoder(O.MODE_DEFLATE, level, 0)
+        tot = 0
+        for i in rng:
+            out = enc.encode(mv[i * UNIT : (i + 1) * UNIT], UNIT + 1024, O.OP_FINISH)[0]
+            tot += len(out)
+            enc.reset()
+        enc.close()
+        return tot
+
+    try:
+        with ThreadPoolExecutor(threads) as ex:
+            t0 = time.perf_counter()
+            comp = sum(ex.map(work_oracle, [range(k, m, threads) for k in range(threads)]))
+            dt = time.perf_counter() - t0
+        res["value"] = round(m * UNIT / dt / 1e9, 3)
+        res["ratio"] = round(comp / (m * UNIT), 4)
+        res["sample"] = f"first {m} units through oracle/oracle_deflate.c (level {level}, raw deflate), one encoder per thread reset per unit"
+    except Exception as e:  # the oracle's Python wrapper may differ: the system zlib figure stands alone then
+        res["value"] = res["system_zlib"]["value"]
+        res["sample"] = f"system zlib only (oracle encoder not timed: {e})"
     return res
 
 
@@ -360,6 +417,7 @@ def main():
     ap.add_argument("--extra", type=int, default=1, help="also measure the configs[1] variants (stored, fixed)")
     ap.add_argument("--cpu-sample", type=int, default=65536, help="units the CPU baseline decodes (about 10-30 s of CPU work in total)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--mixed-units", type=int, default=131072, help="several GPUs: units per GPU of the mixed gzip+zstd workload (configs[4]: 1 M frames over 8 GPUs)")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)  # set by self_launch() on the ranks it starts
     args = ap.parse_args()
 
@@ -415,6 +473,8 @@ def main():
     kinds = [args.workload]
     if args.extra and world == 1:  # every BASELINE config in the one run the driver makes: cfg1 (stored, fixed), cfg4 (mixed), cfg3 (encode)
         kinds += [k for k in ("stored", "fixed", "mixed", "encode") if k != args.workload]
+    elif args.extra and world > 1 and args.workload != "mixed":
+        kinds += ["mixed"]  # configs[4] is the one config that is DEFINED on several GPUs: it rides in every multi-GPU run, at its per-GPU size
     results = {}
     cpu = None
     cpu_extra = {}
@@ -423,14 +483,32 @@ def main():
         if kind == "encode":
             res = run_encode(torch, compu_amd, d_expect, n_units, steps, args.warmup, dist, level=args.encode_level)
             res["steps"] = steps
+            res["units_per_gpu"] = n_units
             results[kind] = res
             log(f"[bench] encode: kernel {res['kernel_ms_avg']:.3f} ms avg, ratio {res['comp_bytes'] / res['out_bytes']:.3f}, verified={res['verified']}")
+            if rank == 0 and world == 1 and not args.no_cpu:
+                c = cpu_baseline_encode(payload, args.cpu_sample // 4, ncpu, level=args.encode_level)
+                if kind == args.workload:
+                    cpu = c
+                else:
+                    cpu_extra[kind] = c
             continue
-        packed, offs, lens = make_workload(kind, payload, n_units, threads, first_unit)
-        res = run_workload(torch, compu_amd, packed, offs, lens, d_expect, n_units, steps, args.warmup, dist, fmt=0 if kind == "mixed" else -15)
+        k_units, k_first, k_payload, k_expect = n_units, first_unit, payload, d_expect
+        if kind == "mixed" and world > 1 and kind != args.workload:
+            # its own shard: units [rank * M, (rank + 1) * M) of the mixed stream (the headline workload's payload is dropped first)
+            k_first, k_units = shard.weak_shard(args.mixed_units, rank)
+            if k_units != n_units:
+                del d_expect
+                k_payload = synth.payloads(k_units, first_unit=k_first, threads=threads)
+                k_expect = torch.from_numpy(k_payload).to(torch.device("cuda", local_rank))
+        packed, offs, lens = make_workload(kind, k_payload, k_units, threads, k_first)
+        res = run_workload(torch, compu_amd, packed, offs, lens, k_expect, k_units, steps, args.warmup, dist, fmt=0 if kind == "mixed" else -15)
         res["steps"] = steps
+        res["units_per_gpu"] = k_units
         results[kind] = res
         log(f"[bench] {kind}: kernel {res['kernel_ms_avg']:.3f} ms avg, verified={res['verified']}")
+        if rank == 0 and world == 1 and not args.no_cpu and kind in ("stored", "fixed") and kind != args.workload:
+            cpu_extra[kind] = cpu_baseline(packed, offs, lens, args.cpu_sample // 4, threads=ncpu, kind=kind, probes=False)
         if rank == 0 and world == 1 and not args.no_cpu and kind in (args.workload, "mixed"):
             uk = None
             if kind == "mixed":
@@ -444,12 +522,17 @@ def main():
         del packed
 
     main_res = results[args.workload]
-    rank_ms = [main_res["kernel_ms_avg"]]
-    if dist is not None:  # every rank's mean kernel time (the ranks run the same number of units: the spread is the devices')
-        t = torch.zeros(world, dtype=torch.float64, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
-        t[rank] = main_res["kernel_ms_avg"]
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        rank_ms = [float(x) for x in t.cpu()]
+    rank_ms_of = {}
+    for k, r in results.items():  # every rank's mean kernel time per workload (the ranks run the same number of units: the spread is the devices')
+        rank_ms_of[k] = [r["kernel_ms_avg"]]
+        if dist is not None:
+            t = torch.zeros(world + 1, dtype=torch.float64, device=torch.device("cuda", local_rank) if dist.get_backend() == "nccl" else "cpu")
+            t[rank] = r["kernel_ms_avg"]
+            t[world] = 0.0 if r["verified"] else 1.0
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            rank_ms_of[k] = [float(x) for x in t[:world].cpu()]
+            r["verified"] = bool(r["verified"]) and float(t[world]) == 0.0  # every rank's verification
+    rank_ms = rank_ms_of[args.workload]
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -516,6 +599,9 @@ def main():
                 "kernel": {"mixed": "chip::route_kernel + chip::inflate_kernel + chip::zstd_kernel", "encode": "chip::deflate_kernel" if args.encode_level == 1 else "chip::deflate_dyn_kernel"}.get(k, "chip::inflate_kernel"),
                 "traffic": None,
                 "cpu_baseline": cpu_extra.get(k),
+                "units_per_gpu": r["units_per_gpu"],
+                "kernel_ms_avg_per_rank": {"min": round(min(rank_ms_of[k]), 4), "max": round(max(rank_ms_of[k]), 4)},
+                "frac_of_n_gpus_peak": round((r["comp_bytes"] + r["out_bytes"]) * world / (max(rank_ms_of[k]) * 1e-3) / 1e9 / (HBM_PEAK_GBPS * world), 5),
                 "verified": r["verified"],
             }
             for k, r in results.items()
@@ -532,8 +618,9 @@ def main():
             same = args.units == 65536
             line["roofline"]["traffic"] = tr.get(args.workload, {}).get("hbm_bytes_per_launch") if same else None
             line["roofline"]["traffic_source"] = tr.get("source")
+            line["roofline"]["traffic_build"] = tr.get("build")  # the commit the PMC passes were taken on (the timing is this run's)
             for k in line["workloads"]:
-                line["workloads"][k]["traffic"] = tr.get(k, {}).get("hbm_bytes_per_launch") if same else None
+                line["workloads"][k]["traffic"] = tr.get(k, {}).get("hbm_bytes_per_launch") if same and line["workloads"][k]["units_per_gpu"] == 65536 else None
         except Exception:
             pass
     print(json.dumps(line), flush=True)

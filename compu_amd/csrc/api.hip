@@ -167,23 +167,11 @@ int chip_decode_batch_ex(int format, uint32_t flags, size_t n, const void *in_ba
     case CHIP_FMT_GZIP:
     case CHIP_FMT_AUTO: e = launch_inflate(a, (hipStream_t)stream); break;
     case CHIP_FMT_ZSTD: e = launch_zstd_decode(a, 0, (hipStream_t)stream); break;
-    case CHIP_FMT_DETECT: {
+    case CHIP_FMT_DETECT:
         // Detection::detect routes every unit: one pass buckets the batch by format, then each decoder runs over its own
-        // (homogeneous) list of units
-        uint32_t *sel_i = nullptr, *sel_z = nullptr, *counts = nullptr;
-        e = route_scratch((hipStream_t)stream, n, &sel_i, &sel_z, &counts);
-        if (e == hipSuccess) e = launch_route(a, sel_i, sel_z, counts, (hipStream_t)stream);
-        BatchArgs ai = a, az = a;
-        ai.format = CHIP_FMT_AUTO;
-        ai.sel = sel_i;
-        ai.sel_n = counts;
-        az.format = CHIP_FMT_ZSTD;
-        az.sel = sel_z;
-        az.sel_n = counts + 1;
-        if (e == hipSuccess) e = launch_inflate(ai, (hipStream_t)stream);
-        if (e == hipSuccess) e = launch_zstd_decode(az, 0, (hipStream_t)stream);
+        // (homogeneous) list of units -- all of it one critical section of the (device, stream) slot (inflate.hip)
+        e = launch_routed(a, (hipStream_t)stream);
         break;
-    }
     default: return CHIP_E_INVALID;
     }
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;

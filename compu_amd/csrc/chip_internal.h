@@ -99,6 +99,8 @@ hipError_t launch_zstd_decode(const BatchArgs &a, int window_log_max, hipStream_
 hipError_t launch_route(const BatchArgs &a, uint32_t *sel_inflate, uint32_t *sel_zstd, uint32_t *counts, hipStream_t stream);
 // device scratch of a routed batch on `stream`, cached with the inflate slot: two index lists of n entries + 2 counters
 hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts);
+// a whole CHIP_FMT_DETECT batch (router + both decoders over their lists) under one lock of the (device, stream) slot
+hipError_t launch_routed(const BatchArgs &a, hipStream_t stream);
 hipError_t launch_detect(size_t n, const uint8_t *in_base, const uint64_t *in_off, const uint32_t *in_len, int32_t *kind,
                          hipStream_t stream);
 hipError_t launch_deflate_l1(const BatchArgs &a, int level, uint32_t flags, uint32_t check_seed, uint64_t total_before,

@@ -34,6 +34,7 @@ namespace chip {
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_u __attribute__((aligned(1)));  // at any byte address (gfx950 takes any alignment for global and LDS accesses)
+typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 template <typename T>
 __device__ __forceinline__ GAS T *rdfirst_gptr(T *p)
 {
@@ -1226,7 +1227,6 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
 
 // ---- tokens kernel only: a unit's token stream in the arena, its record -------------------------------------------------------
 // (see chip_internal.h for the record's layout; every member is wave-uniform)
-typedef u32x4 u32x4_a4 __attribute__((aligned(4)));
 struct Emit {
     uint32_t *arena = nullptr;  // token arena, `arena_words` long, handed out in pieces of PIPE_ARENA_WORDS through counters[1]
     uint32_t arena_words = 0;
@@ -1239,6 +1239,43 @@ struct Emit {
     uint32_t ext_off = 0, ext_n = 0;  // the open run of tokens (ext_n == 0: none)
     bool fail = false;          // the unit does not fit the record / the arena
 };
+
+// The tokens of a walk round's true stream, piece by piece (lane n copies the n-th piece from the row it lies in), to dst[0 .. ntok)
+// in stream order.  A row holds four tokens per 16 bytes (row_word): a piece is up to three single tokens, whole groups of four, up
+// to three single tokens.  The loads go out in batches (the six singles and four groups, then four groups at a time) before the
+// first store waits for one: the copy costs a handful of memory round trips, not one per group.
+__device__ __forceinline__ void copy_pieces(uint32_t *dst_, const uint32_t *rows_, const PieceLane &pl)
+{
+    GAS uint32_t *const dst = (GAS uint32_t *)dst_;
+    GAS const uint32_t *const row = (GAS const uint32_t *)rdfirst_gptr(rows_) + row_base(pl.node);
+    const uint32_t k0 = pl.e_a0, d0 = pl.first, cnt = pl.cnt;
+    uint32_t hk = (4u - (k0 & 3u)) & 3u;
+    hk = hk < cnt ? hk : cnt;                        // single tokens in front
+    const uint32_t kb = k0 + hk, nb4 = (cnt - hk) >> 2, tk = (cnt - hk) & 3u;  // first whole group, whole groups, single tokens behind
+    const uint32_t kt = kb + 4u * nb4, db = d0 + hk, dt = db + 4u * nb4;
+    uint32_t h[3] = {0, 0, 0}, t[3] = {0, 0, 0};
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        if (j < hk) h[j] = row[row_word(k0 + j)];
+        if (j < tk) t[j] = row[row_word(kt + j)];
+    }
+    for (uint32_t i = 0; __any(i < nb4); i += 4u) {
+        u32x4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++) {
+            v[j] = u32x4{0, 0, 0, 0};
+            if (i + j < nb4) v[j] = *(GAS const u32x4 *)(row + 8u * (kb + 4u * (i + j)));  // row_word(k) = 8 k for k = 0 mod 4
+        }
+#pragma unroll
+        for (uint32_t j = 0; j < 4; j++)
+            if (i + j < nb4) *(GAS u32x4_a4 *)(dst + db + 4u * (i + j)) = v[j];
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < 3; j++) {
+        if (j < hk) dst[d0 + j] = h[j];
+        if (j < tk) dst[dt + j] = t[j];
+    }
+}
 
 __device__ __forceinline__ void emit_segment(Emit &E, uint32_t w0, uint32_t w1)
 {
@@ -1283,35 +1320,7 @@ __device__ CHIP_PHASE_FN bool emit_round(Emit &E, const uint32_t *rows_, const P
         E.end = base + PIPE_ARENA_WORDS;
     }
     if (E.ext_n == 0) E.ext_off = E.cur;
-    GAS uint32_t *const dst = (GAS uint32_t *)rdfirst_gptr(E.arena) + E.cur;
-    GAS const uint32_t *const row = (GAS const uint32_t *)rdfirst_gptr(rows_) + row_base(pl.node);
-    uint32_t k = pl.e_a0, d = pl.first;
-    const uint32_t endk = pl.e_a0 + pl.cnt;
-    // a row holds four tokens per 16 bytes (row_word): single tokens up to the first whole group, whole groups, single tokens
-#pragma unroll
-    for (int h = 0; h < 3; h++) {
-        if (k < endk && (k & 3u)) {
-            dst[d] = row[row_word(k)];
-            k++;
-            d++;
-        }
-    }
-    while (__any(k + 4u <= endk)) {
-        if (k + 4u <= endk) {
-            const u32x4 v = *(GAS const u32x4 *)(row + 8u * k);  // row_word(k) = 8 k for k = 0 mod 4
-            *(GAS u32x4_a4 *)(dst + d) = v;
-            k += 4u;
-            d += 4u;
-        }
-    }
-#pragma unroll
-    for (int h = 0; h < 3; h++) {
-        if (k < endk) {
-            dst[d] = row[row_word(k)];
-            k++;
-            d++;
-        }
-    }
+    copy_pieces(rdfirst_ptr(E.arena) + E.cur, rows_, pl);
     E.cur += ntok;
     E.ext_n += ntok;
     return true;
@@ -1862,12 +1871,13 @@ bool pipe_enabled()
 }
 }  // namespace
 
-hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts)
+namespace {
+// (caller holds g_slot_mu)
+hipError_t route_scratch_locked(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts)
 {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
-    std::lock_guard<std::mutex> lk(g_slot_mu);
     LaunchSlot &sl = g_slots[{dev, stream}];
     if (n > sl.route_cap) {
         // work queued on the stream may still read the old lists: let it finish before they go
@@ -1883,6 +1893,37 @@ hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, u
     *sel_inflate = sl.route + 4;
     *sel_zstd = sl.route + 4 + sl.route_cap;
     return hipSuccess;
+}
+hipError_t launch_inflate_locked(const BatchArgs &a, hipStream_t stream);
+}  // namespace
+
+hipError_t route_scratch(hipStream_t stream, size_t n, uint32_t **sel_inflate, uint32_t **sel_zstd, uint32_t **counts)
+{
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    return route_scratch_locked(stream, n, sel_inflate, sel_zstd, counts);
+}
+
+// A CHIP_FMT_DETECT batch: the router's lists and counters belong to (device, stream), so taking them, the counters' reset, the
+// router and both decoders' launches are ONE critical section -- another host thread's routed batch on the same stream cannot put
+// its reset or its router between this batch's router and this batch's decoders (which would then read the other batch's lists),
+// nor free lists that these launches are about to read.  Replaces the routing of src/decoder/mod.rs:28-114 for a whole batch.
+hipError_t launch_routed(const BatchArgs &a, hipStream_t stream)
+{
+    if (a.n == 0) return hipSuccess;
+    std::lock_guard<std::mutex> lk(g_slot_mu);
+    uint32_t *sel_i = nullptr, *sel_z = nullptr, *counts = nullptr;
+    hipError_t e = route_scratch_locked(stream, a.n, &sel_i, &sel_z, &counts);
+    if (e == hipSuccess) e = launch_route(a, sel_i, sel_z, counts, stream);
+    BatchArgs ai = a, az = a;
+    ai.format = CHIP_FMT_AUTO;
+    ai.sel = sel_i;
+    ai.sel_n = counts;
+    az.format = CHIP_FMT_ZSTD;
+    az.sel = sel_z;
+    az.sel_n = counts + 1;
+    if (e == hipSuccess) e = launch_inflate_locked(ai, stream);
+    if (e == hipSuccess) e = launch_zstd_decode(az, 0, stream);
+    return e;
 }
 
 hipError_t release_inflate_scratch()
@@ -1929,6 +1970,12 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
     // stream synchronisation in slot_for() only covers work that is already queued).  The counter reset and the kernel also
     // have to reach the stream back to back.
     std::lock_guard<std::mutex> lk(g_slot_mu);
+    return launch_inflate_locked(a, stream);
+}
+
+namespace {
+hipError_t launch_inflate_locked(const BatchArgs &a, hipStream_t stream)
+{
     LaunchSlot sl;
     hipError_t e = slot_for(stream, a.n, sl);
     if (e != hipSuccess) return e;
@@ -1968,5 +2015,6 @@ hipError_t launch_inflate(const BatchArgs &a, hipStream_t stream)
     hipLaunchKernelGGL(inflate_kernel, dim3(blocks), dim3(64), 0, stream, a, sl.scratch, sl.counter);
     return hipGetLastError();
 }
+}  // namespace
 
 }  // namespace chip

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_two_ranks_started_by_bench_emit_one_parsed_line(gpu):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BENCH_DEVICE_OVERRIDE"] = "0"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--units", "512", "--steps", "2", "--warmup", "1", "--no-cpu"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--units", "512", "--mixed-units", "384", "--steps", "2", "--warmup", "1", "--no-cpu"],
                          capture_output=True, text=True, env=env, timeout=540)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
@@ -30,4 +30,8 @@ def test_two_ranks_started_by_bench_emit_one_parsed_line(gpu):
     spread = line["roofline"]["kernel_ms_avg_per_rank"]
     assert 0 < spread["min"] <= spread["max"]
     assert line["roofline"]["frac_of_n_gpus_peak"] > 0
-    assert set(line["workloads"]) == {"dynamic"}  # side workloads are single-GPU lines
+    # configs[4] (mixed gzip + zstd, sharded) rides in every multi-GPU run at its own per-GPU size, with its own per-rank times
+    assert set(line["workloads"]) == {"dynamic", "mixed"}
+    mixed = line["workloads"]["mixed"]
+    assert mixed["units_per_gpu"] == 384 and mixed["verified"] is True and mixed["frac_of_n_gpus_peak"] > 0
+    assert 0 < mixed["kernel_ms_avg_per_rank"]["min"] <= mixed["kernel_ms_avg_per_rank"]["max"]

@@ -96,9 +96,10 @@ def test_raw_deflate_small_units(gpu, alice):
         assert outs[i] == ref[i][0] and iu[i] == ref[i][1] and st[i] == ref[i][2], i
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(1500)
 def test_full_size_batches_match_the_oracle(gpu):
-    """BASELINE.json's full size -- 65,536 units x 64 KiB -- for the dynamic-Huffman config and the mixed gzip+zstd config:
+    """BASELINE.json's full size -- 65,536 units x 64 KiB -- for configs[1] (stored, fixed Huffman), the dynamic-Huffman config
+    and the mixed gzip+zstd config:
     the GPU output equals the payload on the device, the oracle's output of the same units equals the payload on the host
     (so GPU == oracle, byte for byte, without moving 4 GiB twice), and out_len / in_used / status equal the oracle's."""
     import compu_amd
@@ -112,7 +113,7 @@ def test_full_size_batches_match_the_oracle(gpu):
     d_pay = gpu.from_numpy(pay).to(dev)
     ooff = np.arange(n, dtype=np.uint64) * synth.UNIT
     caps = np.full(n, synth.UNIT, np.uint32)
-    for kind in ("dynamic", "mixed"):
+    for kind in ("stored", "fixed", "dynamic", "mixed"):
         if kind == "mixed":
             packed, offs, lens = synth.mixed_units(pay, n, threads=threads)
         else:
@@ -570,3 +571,51 @@ def test_concurrent_launches_from_two_host_threads(gpu):
         assert bool((st == 2).all()) and bool((ol == 65536).all()), m
     m = big_n[-1]
     assert gpu.equal(big_out[: m * 65536].view(m // n, n * 65536), want.unsqueeze(0).expand(m // n, -1))
+
+
+@pytest.mark.gpu
+def test_concurrent_routed_batches_of_different_sizes_on_one_stream(gpu):
+    """Two host threads send CHIP_FMT_DETECT batches of different sizes to the same stream at the same time.  The router's index
+    lists and counters belong to (device, stream): taking them, the counters' reset, the router and both decoders' launches are one
+    critical section, so neither batch may decode the other's lists (the race survived on this path).  Results are
+    compared with the payload and with a single-threaded run."""
+    import threading
+
+    import compu_amd
+    from bench_support import synth
+
+    dev = "cuda:0"
+    sizes = [320, 1100]
+    jobs = []
+    for k, n in enumerate(sizes):
+        pay = synth.payloads(n, first_unit=1000 * k)
+        packed, offs, lens = synth.mixed_units(pay, n, first_unit=1000 * k)
+        jobs.append(dict(
+            n=n, want=gpu.from_numpy(pay).to(dev), d_in=gpu.from_numpy(packed).to(dev), d_off=gpu.from_numpy(offs.astype(np.int64)).to(dev),
+            d_len=gpu.from_numpy(lens.astype(np.int32)).to(dev), ooff=gpu.arange(n, dtype=gpu.int64, device=dev) * 65536,
+            caps=gpu.full((n,), 65536, dtype=gpu.int32, device=dev), out=gpu.zeros(n * 65536, dtype=gpu.uint8, device=dev), lens=lens))
+    single = []
+    for j in jobs:  # the single-threaded answer
+        ol, iu, st = compu_amd.decode_batch(0, j["d_in"], j["d_off"], j["d_len"], j["out"], j["ooff"], j["caps"])
+        gpu.cuda.synchronize()
+        assert bool((st == 2).all()) and gpu.equal(j["out"], j["want"])
+        single.append((ol.clone(), iu.clone(), st.clone()))
+        j["out"].zero_()
+    res = [None, None]
+
+    def work(k):
+        j = jobs[k]
+        for _ in range(25):
+            res[k] = compu_amd.decode_batch(0, j["d_in"], j["d_off"], j["d_len"], j["out"], j["ooff"], j["caps"])
+
+    compu_amd.trim()  # the lists are allocated (and grown by the larger batch) while both threads launch
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    gpu.cuda.synchronize()
+    for k, j in enumerate(jobs):
+        ol, iu, st = res[k]
+        assert gpu.equal(st, single[k][2]) and gpu.equal(ol, single[k][0]) and gpu.equal(iu, single[k][1]), k
+        assert gpu.equal(j["out"], j["want"]), k
