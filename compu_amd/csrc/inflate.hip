@@ -250,26 +250,24 @@ __device__ __forceinline__ int canon_prep(uint32_t *count, const uint8_t *lens, 
         if (l) atomicAdd(&count[l], 1u);
     }
     WSYNC();
-    uint32_t code = 0, off = 0, maxlen = 0, mynext = 0;
-    int left = 1;
-    bool over = false;
-    for (uint32_t l = 1; l <= 15; l++) {
-        const uint32_t c = rdfirst(count[l]);  // every lane reads the same word: say that it is uniform
-        if (c) maxlen = l;
-        left = (left << 1) - (int)c;
-        if (left < 0) over = true;
-        if (lane == l) mynext = off;
-        if (lane == 0) H.offs[l] = off;
-        off += c;
-        code += c;
-        if (lane == 0) H.limit15[l] = code << (15 - l);
-        code <<= 1;
+    // Lane l (1..15) holds the count of length l.  offs[l] = symbols of shorter lengths; limit15[l] = sum over j <= l of
+    // count[j] << (15 - j): the end of the code space that lengths <= l take, aligned to 15 bits.  zlib's running `left` is
+    // (2^15 - limit15[l]) >> (15 - l): the set is over-subscribed when some limit15[l] exceeds 2^15 and incomplete when
+    // limit15[15] stays below it.  (Two wave prefix sums instead of a 15-step chain of LDS reads and scalar updates.)
+    const uint32_t c = lane >= 1 && lane <= 15 ? count[lane] : 0u;
+    const uint32_t cincl = wave_incl_scan(c);
+    const uint32_t off = cincl - c;
+    const uint32_t lim = wave_incl_scan(lane <= 15 ? c << (15u - (lane & 15u)) : 0u);
+    const uint32_t present = (uint32_t)__ballot(c != 0);
+    const uint32_t maxlen = present ? 31u - (uint32_t)__clz((int)present) : 0u;
+    const bool over = __any(lane <= 15 && lim > 32768u);
+    const int left = rdlane(lim, 15) < 32768u ? 1 : 0;
+    uint32_t mynext = off;
+    if (lane <= 15) {
+        H.limit15[lane] = lim;
+        H.offs[lane] = off;
     }
-    if (lane == 0) {
-        H.limit15[0] = 0;
-        H.offs[0] = 0;
-        H.maxlen = maxlen;
-    }
+    if (lane == 0) H.maxlen = maxlen;
     WSYNC();
     if (maxlen == 0) return 1;
     if (over) return -1;
@@ -278,7 +276,8 @@ __device__ __forceinline__ int canon_prep(uint32_t *count, const uint8_t *lens, 
     for (int base = 0; base < n; base += 64) {
         int s = base + (int)lane;
         uint32_t l = s < n ? lens[s] : 0;
-        for (uint32_t ll = 1; ll <= maxlen; ll++) {
+        for (uint32_t pm = present & 0xfffeu; pm; pm &= pm - 1u) {  // the lengths that occur
+            const uint32_t ll = (uint32_t)__builtin_ctz(pm);
             uint64_t m = __ballot(l == ll);
             uint32_t bp = rdlane(mynext, ll);
             if (l == ll) sorted[bp + __popcll(m & lanemask_lt())] = make((uint32_t)s, l);
@@ -1576,9 +1575,24 @@ __device__ __attribute__((always_inline)) void inflate_unit(const BatchArgs &a, 
                 const uint32_t tl = cl + eb;
                 const uint32_t run = sym < 16 ? 1u : (sym == 18 ? 11u : 3u) + bfe(lo, cl, eb);
                 const uint32_t nx = lane + tl;
-                uint64_t onm = 0;
-                for (uint32_t cur = 0; cur < 64u; cur = rdlane(nx, cur)) onm |= 1ull << cur;
-                const bool on = (onm >> lane) & 1ull;
+                // The symbols really present start at 0, nx(0), nx(nx(0)), ...: lane n finds the n-th of these positions (powers of nx
+                // by doubling, composed along the bits of n; 64 = the chain has left the 64 positions) and flags it.
+                uint32_t nth = 0;
+                {
+                    uint32_t pw = nx < 64u ? nx : 64u;
+#pragma unroll
+                    for (int r = 0; r < 6; r++) {
+                        const uint32_t g1 = lane_gather(pw, nth & 63u), g2 = lane_gather(pw, pw & 63u);
+                        if ((lane >> r) & 1u) nth = nth < 64u ? g1 : 64u;
+                        pw = pw < 64u ? g2 : 64u;
+                    }
+                }
+                uint8_t *const onflag = (uint8_t *)L.hdr.count;  // 64 bytes (the counts are not in use here)
+                if (lane < 16) L.hdr.count[lane] = 0;
+                LSYNC();
+                if (nth < 64u) onflag[nth] = 1;
+                LSYNC();
+                const bool on = onflag[lane] != 0;
                 const uint32_t c = on ? run : 0u;
                 const uint32_t incl = wave_incl_scan(c);
                 const uint32_t start = have + incl - c;
