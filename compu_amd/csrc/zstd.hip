@@ -1737,10 +1737,13 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
     status = CHIP_FINISHED;
 done:
     if ((a.flags & F_COMPU_STATUS) && status != CHIP_FINISHED) {
-        // compu looks at the output first: whatever ZSTD_decompressStream returned, an output buffer that is full means
-        // NeedOutput (src/decoder/zstd.rs:121-133).  libzstd hands on whole blocks in front of an error.
-        const uint32_t ready = status < 0 ? blk0 : opos;
-        if (ready >= cap) {
+        // compu looks at the output first (src/decoder/zstd.rs:121-133): output.pos == output.size is NeedOutput whatever
+        // ZSTD_decompressStream returned.  An error return leaves output.pos as compu set it, 0 -- libzstd decodes a block only once the one
+        // in front has been flushed whole, and returns from inside its loop -- so an error stays an error (also behind blocks that fill
+        // the range exactly) unless the range is empty; checked against the system's libzstd in tests/test_oracle_zstd.py.
+        if (status < 0) {
+            if (cap == 0) status = CHIP_NEED_OUTPUT;
+        } else if (opos >= cap) {
             status = CHIP_NEED_OUTPUT;
             opos = cap;
         }

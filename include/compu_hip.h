@@ -164,8 +164,10 @@ int chip_decode_batch(int format, size_t n, const void *in_base, const uint64_t 
  *   deflate / zlib / gzip (src/decoder/mod.rs:475-483): zlib's Z_OK with avail_in == 0 is NeedInput even when it was the
  *     output that filled (in_used[i] is then zlib's count: every bit of the token during which the room ran out, rounded up
  *     to a byte), and a unit without any input is NeedOutput (zlib's Z_BUF_ERROR);
- *   zstd (src/decoder/zstd.rs:121-133): an output range that is full is NeedOutput whatever else ZSTD_decompressStream said --
- *     an error behind whole blocks that fill out_cap[i] exactly, a truncated frame whose bytes so far fill it.
+ *   zstd (src/decoder/zstd.rs:121-133): compu compares output.pos with output.size before it looks at the return value -- a
+ *     truncated frame whose bytes so far fill out_cap[i] exactly is NeedOutput; an error stays the error, also behind blocks
+ *     that fill out_cap[i] exactly (ZSTD_decompressStream returns an error before it writes output.pos, so compu sees 0),
+ *     except for an empty output range (0 == 0: NeedOutput).
  * Everything else is identical.  Unknown flag bits: CHIP_E_INVALID.
  */
 enum { CHIP_F_COMPU_STATUS = 1 };

@@ -3,6 +3,8 @@
 //! Same shape as `zlib_ng.rs`: one static vtable per format family, the state pointer is the backend's opaque
 //! decoder object, created by the constructor and freed exactly once by `drop_fn`.
 
+extern crate alloc;
+
 use core::ptr;
 
 use super::zlib_common::ZlibMode;
@@ -130,7 +132,9 @@ pub struct BatchResult {
 }
 
 ///Batch format: one of `ZlibMode`'s window-bits values, zstd, or per-unit routing by `Detection::detect`.
-#[derive(Clone, Copy, Debug)]
+///
+///(`ZlibMode` derives only `Copy` and `Clone`, src/decoder/zlib_common.rs:1, so `Debug` is written by hand.)
+#[derive(Clone, Copy)]
 pub enum BatchFormat {
     ///raw deflate / zlib / gzip / zlib-or-gzip, as `Interface::zlib_hip(mode)`
     Zlib(ZlibMode),
@@ -138,6 +142,16 @@ pub enum BatchFormat {
     Zstd,
     ///gzip, zlib and zstd units mixed: each unit goes where `Detection::detect` sends it (src/decoder/mod.rs:28-114)
     Detect,
+}
+
+impl core::fmt::Debug for BatchFormat {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        match self {
+            BatchFormat::Zlib(mode) => write!(f, "Zlib({})", mode.max_bits()),
+            BatchFormat::Zstd => f.write_str("Zstd"),
+            BatchFormat::Detect => f.write_str("Detect"),
+        }
+    }
 }
 
 impl BatchFormat {

@@ -1,5 +1,7 @@
 //! `hip` module: zlib / gzip / raw deflate encoding on an MI355X through `libcompu_hip.so`.
 
+extern crate alloc;
+
 use core::ptr;
 
 use super::{Encode, EncodeOp, EncodeStatus, Encoder, Interface, ZlibOptions, ZlibStrategy};
@@ -100,7 +102,7 @@ fn strategy_tag(strategy: ZlibStrategy) -> core::ffi::c_int {
 
 ///Capacity that always holds the stream of `in_len` input bytes in `opts.mode`.
 pub fn encode_bound(opts: &ZlibOptions, in_len: usize) -> usize {
-    unsafe { sys::chip_encode_bound(opts.mode.max_bits() as _, in_len) }
+    unsafe { sys::chip_encode_bound(opts.mode as _, in_len) }
 }
 
 ///Compresses `units` of `input` into `output`, both in HOST memory, on `device`.  Returns, per unit, the compressed length and the
@@ -126,7 +128,7 @@ pub fn encode_batch_host(opts: &ZlibOptions, device: i32, input: &[u8], units: &
         return Err(-101);
     }
     let rc = unsafe {
-        sys::chip_encode_batch_host(opts.mode.max_bits() as _, opts.compression as _, n, input.as_ptr() as *const _, in_off.as_ptr(), in_len.as_ptr(),
+        sys::chip_encode_batch_host(opts.mode as _, opts.compression as _, n, input.as_ptr() as *const _, in_off.as_ptr(), in_len.as_ptr(),
                                     output.as_mut_ptr() as *mut _, out_off.as_ptr(), out_cap.as_ptr(), out_len.as_mut_ptr(), status.as_mut_ptr(), device, 0)
     };
     if rc != sys::CHIP_OK {
@@ -159,11 +161,11 @@ pub unsafe fn encode_batch_device(opts: &ZlibOptions, n: usize, input: &crate::b
         return Err(-101);
     }
     let rc = if strategy_tag(opts.strategy) == 0 {
-        sys::chip_encode_batch(opts.mode.max_bits() as _, opts.compression as _, n, input.as_ptr() as *const _, in_off.as_ptr() as *const u64,
+        sys::chip_encode_batch(opts.mode as _, opts.compression as _, n, input.as_ptr() as *const _, in_off.as_ptr() as *const u64,
                                in_len.as_ptr() as *const u32, output.as_mut_ptr() as *mut _, out_off.as_ptr() as *const u64, out_cap.as_ptr() as *const u32,
                                out_len.as_mut_ptr() as *mut u32, status.as_mut_ptr() as *mut i32, stream)
     } else {
-        sys::chip_encode_batch_ex(opts.mode.max_bits() as _, opts.compression as _, strategy_tag(opts.strategy), n, input.as_ptr() as *const _,
+        sys::chip_encode_batch_ex(opts.mode as _, opts.compression as _, strategy_tag(opts.strategy), n, input.as_ptr() as *const _,
                                   in_off.as_ptr() as *const u64, in_len.as_ptr() as *const u32, output.as_mut_ptr() as *mut _, out_off.as_ptr() as *const u64,
                                   out_cap.as_ptr() as *const u32, out_len.as_mut_ptr() as *mut u32, status.as_mut_ptr() as *mut i32, stream)
     };

@@ -560,8 +560,9 @@ static int advance(orc_zstd *s)
                 memset(s->out + s->out_len, p[3], bsz);
                 s->out_len += bsz;
             } else {
+                size_t before = s->out_len;
                 int e = decode_compressed_block(s, p + 3, bsz);
-                if (e) return e;
+                if (e) { s->out_len = before; return e; } /* libzstd hands on nothing of a block that fails */
             }
             s->in_pos += 3 + need;
             if (last) {
@@ -608,6 +609,12 @@ orc_decode_t orc_zstd_decode(orc_zstd *s, const uint8_t *in, size_t in_len, uint
     }
     if (!s->err && s->stage != 3) s->err = advance(s);
     size_t avail = s->out_len - s->delivered, n = avail < out_len ? avail : out_len;
+    /* ZSTD_decompressStream decodes a block only when the one before has been flushed whole, and an error return leaves
+     * output->pos as the caller set it (0 in compu's decode_fn, src/decoder/zstd.rs:104-112): the call that gets to the damage -- the
+     * one that could hand on the last good bytes -- reports the error and no output at all; compu then sees pos 0 != size
+     * (checked against the system's libzstd: tests/test_oracle_zstd.py).  Only an empty output range reads as NeedOutput. */
+    int err_now = s->err && s->delivered + n == s->out_len;
+    if (err_now && out_len) n = 0;
     memcpy(out, s->out + s->delivered, n);
     s->delivered += n;
     r.output_remain = out_len - n;
@@ -620,11 +627,11 @@ orc_decode_t orc_zstd_decode(orc_zstd *s, const uint8_t *in, size_t in_len, uint
     r.input_remain = (in_len - taken) + giveback;
     /* ZSTD_decompressStream's return value: 0 = frame done and flushed, error, or a positive hint */
     int done = s->stage == 3 && s->delivered == s->out_len;
-    int is_err = s->err && s->delivered == s->out_len; /* decoded data is flushed before the error shows */
+    int is_err = err_now; /* the good bytes of earlier calls have been handed on; those of this call are not */
     /* src/decoder/zstd.rs:113-135: 0 -> Finished; else output full -> NeedOutput; else not an error
      * -> NeedInput; else Err */
     if (done) r.status = ORC_FINISHED;
-    else if (r.output_remain == 0) r.status = ORC_NEED_OUTPUT;
+    else if (r.output_remain == 0 && !(is_err && out_len)) r.status = ORC_NEED_OUTPUT;
     else if (!is_err) r.status = ORC_NEED_INPUT;
     else { r.status = -1; r.err = -s->err; }
     return r;

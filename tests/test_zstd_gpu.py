@@ -122,8 +122,10 @@ def test_truncated_and_corrupt_frames_match_oracle(gpu, alice):
 
 
 def test_compu_status_flag_puts_a_full_output_first(gpu, alice):
-    """CHIP_F_COMPU_STATUS for zstd (src/decoder/zstd.rs:121-133): a full output range is NeedOutput whatever else happened -- a
-    checksum error behind an exactly sized buffer, a truncated frame whose blocks so far fill it, no room at all."""
+    """CHIP_F_COMPU_STATUS for zstd (src/decoder/zstd.rs:121-133): compu compares output.pos with output.size first.  A truncated frame
+    whose blocks so far fill the range is NeedOutput, and so is anything handed an empty range; an ERROR stays the error -- also behind
+    an exactly sized buffer, because ZSTD_decompressStream returns it before it writes output.pos (compu sees 0).  The expectations are
+    the system libzstd's own answers (zstd_ref.stream_decode_once), the oracle's, and the kernel's."""
     import compu_amd
 
     z = zstd_ref.load()
@@ -132,13 +134,17 @@ def test_compu_status_flag_puts_a_full_output_first(gpu, alice):
     bad_ck = bytearray(good)
     bad_ck[-1] ^= 1
     two = zstd_ref.compress(z, (alice * 3)[:400000], 3, True, False)  # four blocks
-    parts = [bytes(bad_ck), bytes(bad_ck), good, good[:-2], b"\x00\x00\x00\x00", good[:40]]
-    caps = [100000, 100001, 100000, 100000, 0, 0]
+    parts = [bytes(bad_ck), bytes(bad_ck), good, good[:-2], b"\x00\x00\x00\x00", good[:40], bytes(bad_ck)]
+    caps = [100000, 100001, 100000, 100000, 0, 0, 0]
     outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, parts, caps, check_tail=False, flags=compu_amd.F_COMPU_STATUS)
     ref = oracle_zstd_batch(parts, caps)
-    assert [int(x) for x in st] == [r[2] for r in ref] == [1, -22, 2, 1, 1, 1]
+    real = []
+    for p_, c_ in zip(parts, caps):
+        _o, _i, _r, s_, e_ = zstd_ref.stream_decode_once(z, p_, c_)
+        real.append(e_ if s_ is None else s_)
+    assert [int(x) for x in st] == [r[2] for r in ref] == real == [-22, -22, 2, 1, 1, 1, 1]
     outs0, _, _, st0 = run_batch(gpu, FMT_ZSTD, parts, caps, check_tail=False)
-    assert [int(x) for x in st0] == [-22, -22, 2, 0, -10, 0]  # the default names the cause
+    assert [int(x) for x in st0] == [-22, -22, 2, 0, -10, 0, -22]  # the default names the cause
     # a truncated multi-block frame: the whole blocks in front of the cut fill the buffer exactly
     full, _, _, s_full = run_batch(gpu, FMT_ZSTD, [two], [400000], check_tail=False)
     assert s_full[0] == 2
