@@ -5,18 +5,21 @@
 // dynamic-Huffman table build, bitstream decode, LZ77 copy (RFC 1951), and the zlib / gzip
 // wrappers with Adler-32 / CRC-32 verification (RFC 1950 / 1952).
 //
-// Data flow per wave:  compressed bytes --(coalesced dword loads)--> a ring of the input in LDS
-//   --> canonical-Huffman tables in LDS --> the ROLLING WALK: the block's bits are cut into a fixed grid of
-//   256-bit segments; a lane takes the next unclaimed segment, decodes the token chain that starts at its
-//   (guessed) first bit, marks the token boundaries it passes inside its own segment, keeps going past
-//   the segment's end until it steps on a boundary marked by the owner of the segment it is in (from there
-//   on the two chains are the same) and then takes the next segment.  Tokens (literal | length, distance)
-//   go to the lane's row of the wave's scratch in HBM/L2 --> when the block (or the scratch) is exhausted the
-//   chain of joins from the block's first bit is followed: that is the true token stream --> it is executed a
-//   chunk (<= 2.5 KB of output) at a time: token output offsets by wave prefix sum, literals and queued
-//   matches assembled in LDS and stored coalesced into the unit's output range in HBM (the LZ77 window is the
-//   output itself).
+// Data flow per wave (inflate_kernel, the one-kernel path):  block header --> canonical-Huffman tables in LDS (two-level, see below)
+//   --> per block a sequence of SUPER-ROUNDS.  A super-round stages the next 64 x 384 bits of input in LDS (coalesced dword loads)
+//   from the true token boundary B on; lane i decodes the token chain that starts at B + 384 i (a guess, except for lane 0), marks
+//   the token boundaries it passes inside its own 384-bit segment in a bit map of the staged input, and keeps going past the
+//   segment's end until it steps on a boundary marked by the owner of the segment it is in (from there on the two chains are the
+//   same), at most 1536 bits further (3072 in fixed-Huffman blocks).  Tokens (literal | length, distance) go to the lane's row of
+//   the wave's scratch in HBM / L2, 16 bytes per four tokens.  The chain of joins from lane 0 is the true token stream; it is found
+//   in registers (pointer doubling with ds_bpermute) and executed a chunk (<= 3.5 KB of output) at a time: 64 tokens per step
+//   fetched through an LDS-DMA ring, output offsets by wave prefix sum, literals and queued matches assembled in LDS and stored
+//   coalesced into the unit's output range in HBM (the LZ77 window is the output itself).
 // The grid is persistent: waves take units from a counter, so the token scratch is one slot per resident wave.
+//
+// tokens_kernel is the same decoder with the execution left out: it appends a unit's true tokens to an arena in stream order and
+// leaves a record; lz77_kernel (lz77.hip) executes them in an LDS image of the unit's output.  This two-kernel pipeline is behind
+// CHIP_INFLATE_PIPE=1 (built, parity-green, measured slower than the one-kernel path in round 4).
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -158,8 +161,8 @@ constexpr size_t ROWS_WORDS = (size_t)64 * ROW_TOKENS;
 __device__ __forceinline__ uint32_t row_base(uint32_t l) { return (l >> 3) * (8u * ROW_TOKENS) + (l & 7u) * 4u; }
 __device__ __forceinline__ uint32_t row_word(uint32_t k) { return k + (k >> 2) * 28u; }  // 32 * (k / 4) + k % 4
 
-// token: [8:0] literal byte, or match length 3..258; [9] match; [25:10] match distance - 1; [31:26] bits the token took in the
-// stream (the walk's flush preparation finds a piece's entry token by adding these up)
+// token: [8:0] literal byte, or match length 3..258; [9] match; [25:10] match distance - 1 (a piece's entry token in a joined lane's
+// row is found from the popcount of the owner's boundary marks, not from the tokens)
 
 struct HuffMeta {
     uint32_t limit15[16];  // [l] = end (exclusive) of the 15-bit-aligned code space of lengths <= l; [0] = 0
@@ -1128,7 +1131,9 @@ __device__ CHIP_PHASE_FN uint32_t walk_round(WaveLds &L, const InWin &w, const u
     bool full = false;  // the lane's row is full
     while (__any(run)) {
         STAT_ADD(11, 1);
-        uint32_t t4[4] = {0, 0, 0, 0};
+        uint32_t t4[4];  // (a slot whose token is not taken keeps whatever its registers hold: nothing reads a row behind its lane's count)
+#pragma unroll
+        for (int k = 0; k < 4; k++) asm volatile("" : "=v"(t4[k]));
         const uint32_t ng = nst;
         if (run) {
             if (nst + 4u > ROW_TOKENS) {
@@ -1803,7 +1808,7 @@ std::mutex g_slot_mu;
 std::map<std::pair<int, hipStream_t>, LaunchSlot> g_slots;
 
 // The slot of (current device, stream), with token scratch for min(n, resident waves) waves: a streaming decoder
-// (batches of one) holds 200 KB, not the 0.8 GB a full grid needs; the scratch grows when a larger batch arrives.
+// (batches of one) holds one 64 KiB slot, not the 270 MB a full grid needs; the scratch grows when a larger batch arrives.
 // (caller holds g_slot_mu)
 hipError_t slot_for(hipStream_t stream, uint32_t n, LaunchSlot &out)
 {
