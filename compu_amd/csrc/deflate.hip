@@ -23,7 +23,10 @@ namespace chip {
 
 namespace {
 
-constexpr int HASH_BITS = 12;
+#ifndef CHIP_HASH_BITS
+#define CHIP_HASH_BITS 12
+#endif
+constexpr int HASH_BITS = CHIP_HASH_BITS;
 constexpr uint32_t MIN_MATCH = 4, MAX_MATCH = 258, MAX_DIST = 32768;
 constexpr int OUT_DW = 192;  // LDS bit buffer, dwords (a chunk adds at most 62); with the table and lentab: 10 240 B = sixteen waves per CU
 

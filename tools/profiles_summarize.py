@@ -3,7 +3,7 @@ python tools/profiles_summarize.py <tag>   (run in the dev container after the g
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 
 
@@ -43,9 +43,20 @@ with open(os.path.join(P, f"{tag}_dispatches.csv"), "w") as o:
             wl = "encode"
         o.write(f"{i},{short},{(int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e6:.4f},{wl}\n")
 # 3. PMC passes per workload: FETCH_SIZE / WRITE_SIZE per dispatch of the workload's kernels (the first dispatch is the warm-up)
+import subprocess
+
+try:
+    build = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+except Exception:
+    build = None
 out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) on `python3 bench.py --workload W --steps 3 --warmup 1 --no-cpu "
-                 f"--extra 0` ({tag}, tools/profile_round.sh); counters are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 tallies 128-B "
-                 "requests at 64 B), calibrated on the stored workload whose read bytes are known; Infinity-Cache hits are included in FETCH_SIZE",
+                 f"--extra 0` ({tag}, tools/profile_round.sh); counters are in KiB.  Rule per access shape (measured with tools/exp/fetch_probe.hip, "
+                 f"profiles/{tag}_fetch_probe.txt): FETCH_SIZE reports HALF the bytes of lane-contiguous 16-byte loads (8.0 B per load) and the 64-byte "
+                 "request of a scattered 16-byte load as it is (63.9 B per aligned load, 71.4 B at any alignment).  So the LZ77 source fetches of the "
+                 "inflate kernel -- FETCH_SIZE of the product minus FETCH_SIZE of the -DCHIP_EXP_NO_GLOB build that leaves them out -- are counted "
+                 "once and the rest of the read side twice; workloads without such an ablation (stored, mixed's zstd half, encode) keep the plain "
+                 "doubling, which overstates their gathers.  Infinity-Cache hits are included in FETCH_SIZE",
+       "build": build,
        "unit": "bytes per launch (65536 units)"}
 KERNELS = {"dynamic": ("inflate_kernel",), "stored": ("inflate_kernel",), "fixed": ("inflate_kernel",), "mixed": ("inflate_kernel", "zstd_kernel"), "encode": ("deflate_kernel",)}
 keep = ["Dispatch_Id", "Kernel_Name", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Counter_Name", "Counter_Value"]
@@ -68,8 +79,19 @@ for wl, kernels in KERNELS.items():
                 w = csv.DictWriter(o, keep, extrasaction="ignore")
                 w.writeheader()
                 w.writerows(allrows)
-        rd, wr = int(tot["fetch"] * 1024 * 2), int(tot["write"] * 1024)
+        scat = None
+        try:  # the ablation pass of this workload, when it was taken
+            rr = [r for r in csv.DictReader(open(one(f"{tag}_{wl}_noglob_pmc_fetch/**/*counter_collection.csv"))) if "inflate_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+            rr.sort(key=lambda r: int(r["Dispatch_Id"]))
+            vals = [float(r["Counter_Value"]) for r in rr[1:4]] or [float(r["Counter_Value"]) for r in rr]
+            scat = max(0.0, tot["fetch"] - sum(vals) / len(vals))
+        except (SystemExit, ZeroDivisionError):
+            pass
+        rd = int((tot["fetch"] - (scat or 0.0)) * 1024 * 2 + (scat or 0.0) * 1024)
+        wr = int(tot["write"] * 1024)
         out[wl] = {"fetch_size_kib_raw": tot["fetch"], "write_size_kib": tot["write"], "hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes_per_launch": rd + wr}
+        if scat is not None:
+            out[wl]["source_fetch_kib_raw"] = scat
         if len(kernels) > 1:
             out[wl]["per_kernel_kib"] = per
     except SystemExit as e:
@@ -77,6 +99,17 @@ for wl, kernels in KERNELS.items():
 json.dump(out, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 if os.path.exists(os.path.join(G, f"{tag}_pmc_insts.txt")):
     open(os.path.join(P, f"{tag}_pmc_insts.txt"), "w").write(open(os.path.join(G, f"{tag}_pmc_insts.txt")).read())
+try:  # the access-shape probe: bytes FETCH_SIZE reports per 16-byte load
+    import re
+    log = open(os.path.join(G, f"{tag}_fetch_probe.log")).read()
+    loads = float(re.search(r"loads per kernel: (\d+)", log).group(1))
+    lines = [f"tools/exp/fetch_probe.hip under rocprofv3 --pmc FETCH_SIZE ({tag}); {loads:.0f} 16-byte loads per kernel over a 2 GiB buffer"]
+    for r in csv.DictReader(open(one(f"{tag}_fetch_probe/**/*counter_collection.csv"))):
+        if r["Counter_Name"] == "FETCH_SIZE" and "probe" in r["Kernel_Name"]:
+            lines.append(f"{r['Kernel_Name'][:60]:60s} FETCH_SIZE {float(r['Counter_Value']):12.0f} KiB = {float(r['Counter_Value']) * 1024 / loads:6.2f} B per load")
+    open(os.path.join(P, f"{tag}_fetch_probe.txt"), "w").write("\n".join(lines) + "\n")
+except (SystemExit, OSError, AttributeError) as e:
+    print("fetch probe skipped", e)
 for extra in ("pmc_insts_zstd", "pmc_insts_encode"):
     if os.path.exists(os.path.join(G, f"{tag}_{extra}.txt")):
         open(os.path.join(P, f"{tag}_{extra}.txt"), "w").write(open(os.path.join(G, f"{tag}_{extra}.txt")).read())
