@@ -526,8 +526,13 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             // one unaligned 16-byte load per side: a scattered load costs the L1 a tag lookup per lane and instruction
             // (every lane issues both loads, clamped into the unit, so that waiting for chunk c's bytes leaves chunk
             // c+1's in flight; lanes in the unit's last 15 bytes do not use them)
+#ifdef CHIP_EXP_NO_CAND  // traffic ablation (tools/profile_round.sh): every candidate load reads the lane's own position instead
+            c.qv = *(const U128u *)(gwide + (p < wide_end ? p : wide_end));
+            if constexpr (TWO) c.qv2 = c.qv;
+#else
             c.qv = *(const U128u *)(gwide + (c.q < wide_end ? c.q : wide_end));
             if constexpr (TWO) c.qv2 = *(const U128u *)(gwide + (c.q2 < wide_end ? c.q2 : wide_end));
+#endif
             c.pv = *(const U128u *)(gwide + (p < wide_end ? p : wide_end));
             LSYNC();  // every lookup saw the table as it stood before this chunk (LDS only: the loads stay in flight)
             // The highest position of a slot stands.  (LDS has no 16-bit maximum: all write, a lane that finds a lower lane of

@@ -1566,7 +1566,8 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         if (dropped + ostart + tot > out_limit || (uint64_t)(ostart - block_out0) + tot > BLOCK_MAX) fail = 1;
                         else if (lit_incl > regen - lpos) fail = 2;
                         else if ((uint64_t)ostart + tot > cap) fail = 3;
-                        else if (off > mstart) fail = 4;
+                        else if (off > mstart || off > window) fail = 4;  // beyond the frame's start, or beyond its window: the verdict must not
+                                                                          // depend on how much history a streaming caller has let go (api.hip, dec_compact)
                     }
                     const uint64_t failm = __ballot(fail != 0);
                     if (failm) {

@@ -148,6 +148,11 @@ const char *chip_decoder_strerror(int format, int32_t code);
  *               (zlib: -3 data error; zstd: -(ZSTD_ErrorCode), e.g. -20 corruption, -22 checksum)
  * For CHIP_FMT_ZSTD: on CHIP_NEED_OUTPUT out_len counts whole blocks only, and the unit's range up to
  * out_cap[i] may be used as scratch (regenerated literals are parked at its end while a block decodes).
+ * A block is decoded in the unit's own range, so one that does not fit is CHIP_NEED_OUTPUT at the point
+ * where the room ends -- also when damage lies further on in that block, which libzstd (decoding in a buffer of
+ * its own) would report instead; with room for the frame the verdicts are the same.  A match offset beyond the
+ * frame's Window_Size is -20 even where the bytes exist (RFC 8878 3.1.1.1.2): the verdict never depends on
+ * how much history a streaming caller's decoder still holds.
  * in_base must be 4-byte aligned and its allocation padded to a multiple of 4 bytes.
  * `format` is one CHIP_FMT_* for the whole batch.  `stream` is a hipStream_t (NULL = default
  * stream); the call only enqueues work.  Returns CHIP_OK or a CHIP_E_* code.

@@ -461,7 +461,8 @@ static int decode_compressed_block(orc_zstd *s, const uint8_t *src, size_t n)
             if (llen > regen - lpos) return CORRUPT();
             memcpy(s->out + s->out_len, s->lit + lpos, llen);
             s->out_len += llen; lpos += llen;
-            if (offset > s->out_len - s->frame_start) return CORRUPT();
+            /* beyond the frame's start, or beyond its window (RFC 8878 3.1.1.1.2; libzstd takes whatever its ring still holds) */
+            if (offset > s->out_len - s->frame_start || offset > s->window) return CORRUPT();
             uint8_t *d = s->out + s->out_len;
             const uint8_t *m = d - offset;
             for (uint32_t k = 0; k < mlen; k++) d[k] = m[k];

@@ -148,3 +148,32 @@ def test_status_at_every_capacity_is_the_systems_libzstd():
                         assert got[3] is None and got[4] in (-20, -70), (name, cap, st, err, got[1:])  # ... and only where the oracle is the stricter one
                         lax.add(bytes(c))
     assert len(lax) * 25 < flips, (len(lax), flips, total)
+
+
+def _stream_verdict(decoder, frame, piece, ocap):
+    """-> (output, error code or 0) of feeding `frame` in pieces of `piece` bytes with `ocap` bytes of output room per call"""
+    pos, out = 0, b""
+    for _ in range(200000):
+        chunk = frame[pos : pos + piece]
+        got, ir, orr, st, err = decoder.decode(chunk, ocap)
+        if err:
+            return out, err
+        out += got
+        pos += len(chunk) - ir
+        if st == O.FINISHED:
+            return out, 0
+    raise AssertionError("no end")
+
+
+def test_an_offset_beyond_the_window_is_corruption_however_the_stream_is_sliced():
+    """the verdict on a match that reaches behind the frame's window, but not behind its start, must not depend
+    on how much history the decoder still holds.  Frames written by hand (tests/zstd_ref.py::craft_offset_frame: raw blocks, then
+    one sequence with a chosen offset; window 1 KiB): offsets up to the window decode, anything farther is -20 -- whole, in small
+    pieces, with small output ranges.  (libzstd 1.4.8 copies whatever its ring holds there, without an error: measured when this
+    test was written -- offset 2000 of 2000 bytes returned other bytes than the frame's first three.)"""
+    for blocks, offset, ok in ((2, 1000, True), (2, 1024, True), (2, 1025, False), (2, 1500, False), (2, 2000, False), (2, 2001, False), (1, 900, True), (1, 1001, False)):
+        frame, data = zstd_ref.craft_offset_frame(blocks, 1000, offset)
+        want = data + data[len(data) - offset : len(data) - offset + 3] if ok else None
+        for piece, ocap in ((10**9, 10**6), (7, 10**6), (10**9, 100), (300, 333)):
+            out, err = _stream_verdict(O.ZstdDecoder(), frame, piece, ocap)
+            assert (err == 0) == ok and (not ok or out == want) and (ok or err == -20), (blocks, offset, piece, ocap, err)

@@ -395,3 +395,49 @@ def test_streaming_a_zstd_window_larger_than_the_device_buffer(gpu, alice):
         crc, got, _, peak_dev, _ = _stream_through(compu, dec, comp, 256 << 10, 1 << 20, gpu, every=8)
         assert got == len(data) and crc == want_crc
         assert (16 << 20) <= peak_dev <= (72 << 20), peak_dev
+
+
+def test_an_offset_beyond_the_window_is_corruption_batch_and_stream(gpu):
+    """an offset that reaches behind the frame's window -- but not behind its start -- is corruption in the batch
+    path and in the streaming path alike, before and after the streaming decoder has let history go (it keeps the window; it used to
+    accept such an offset while the bytes happened to be there and reject it after 1 MiB had been dropped).  Frames written by hand
+    (tests/zstd_ref.py::craft_offset_frame; window 1 KiB), verdicts and bytes against the oracle."""
+    import zlib
+
+    import compu_amd as compu
+
+    import torch
+
+    cases = [(2, 1000), (2, 1024), (2, 1025), (2, 1500), (2, 2000), (2, 2001), (1, 900), (1, 1001), (40, 1024), (40, 30000)]
+    frames = [zstd_ref.craft_offset_frame(b, 1000, off)[0] for b, off in cases]
+    caps = [b * 1000 + 64 for b, _ in cases]
+    outs, ol, iu, st = run_batch(torch, FMT_ZSTD, frames, caps, check_tail=False)
+    ref = oracle_zstd_batch(frames, caps)
+    for j, (b, off) in enumerate(cases):
+        r_out, r_used, r_st = ref[j]
+        assert r_st == (2 if off <= min(1024, b * 1000) else -20)
+        assert int(st[j]) == r_st and (r_st != 2 or (outs[j] == r_out and int(iu[j]) == r_used)), (b, off, int(st[j]), r_st)
+    # streaming: 1.6 MB of raw blocks in front of the sequence, so that the decoder has dropped more than 1 MiB by then
+    for off, ok in ((1024, True), (1025, False), (1500, False), (700000, False)):
+        frame, data = zstd_ref.craft_offset_frame(1600, 1000, off)
+        for piece, room in ((64 << 10, 64 << 10), (len(frame), 2 << 20), (5000, 300000)):
+            dec = compu.decoder_interface.zstd_hip()
+            out = bytearray(room)
+            pos, crc, got, err = 0, 0, 0, None
+            for _ in range(100000):
+                chunk = frame[pos : pos + piece]
+                r = dec.decode(chunk, out)
+                if not r.is_ok():
+                    err = r.status.as_raw()
+                    break
+                n = len(out) - r.output_remain
+                crc = zlib.crc32(memoryview(out)[:n], crc)
+                got += n
+                pos += len(chunk) - r.input_remain
+                if r.status == compu.DecodeStatus.Finished:
+                    break
+            if ok:
+                want = data + data[len(data) - off : len(data) - off + 3]
+                assert err is None and got == len(want) and crc == zlib.crc32(want), (off, piece, err, got)
+            else:
+                assert err == -20, (off, piece, err, got)

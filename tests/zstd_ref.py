@@ -70,3 +70,24 @@ def stream_decode_once(z, comp, out_cap):
         st, err = None, -z.ZSTD_getErrorCode(ret)
     z.ZSTD_freeDStream(ds)
     return out, len(comp) - ib.pos, out_cap - ob.pos, st, err
+
+
+def craft_offset_frame(raw_blocks, block_len, offset, window_desc=0x00, fill=None):
+    """A frame written by hand (RFC 8878): `raw_blocks` Raw_Blocks of `block_len` bytes, then one Compressed_Block with no literals
+    and one sequence (literal length 0, match length 3, the given offset > 3 bytes back; all three tables in RLE mode, so the
+    bitstream holds only the offset's extra bits).  No checksum, no content size; window from `window_desc` (0 = 1 KiB).
+    -> (frame, the data of the raw blocks)"""
+    import random
+
+    rnd = random.Random(raw_blocks * 131 + block_len)
+    data = fill if fill is not None else bytes(rnd.randrange(256) for _ in range(raw_blocks * block_len))
+    out = bytearray(b"\x28\xb5\x2f\xfd") + bytes([0x00, window_desc])
+    for k in range(raw_blocks):
+        out += (block_len << 3).to_bytes(3, "little") + data[k * block_len:(k + 1) * block_len]
+    value = offset + 3                      # Offset_Value; > 3: a new offset
+    code = value.bit_length() - 1
+    bits = (value - (1 << code)) | (1 << code)   # the extra bits, then the closing 1 bit above them
+    stream = bits.to_bytes((code + 1 + 7) // 8, "little")
+    body = bytes([0x00, 0x01, 0x54, 0x00, code, 0x00]) + stream  # raw literals of size 0; one sequence; RLE x 3: LL code 0, OF code, ML code 0
+    out += ((len(body) << 3) | (2 << 1) | 1).to_bytes(3, "little") + body
+    return bytes(out), data

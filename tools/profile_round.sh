@@ -23,6 +23,9 @@ done
 for wl in dynamic fixed; do
   COMPU_HIP_LIB=$PWD/compu_amd/libcompu_hip_NO_GLOB.so rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_${wl}_noglob_pmc_fetch -o run --output-format csv -- python3 bench.py --workload $wl --steps 3 --warmup 1 --no-cpu --extra 0 > /dev/null 2>> gpurun_out/${tag}_bench.log || true
 done
+# the encoder's candidate gathers, the same way (-DCHIP_EXP_NO_CAND: every candidate load reads the lane's own position)
+(cd compu_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DCHIP_EXP_NO_CAND -o ../libcompu_hip_NO_CAND.so *.hip 2>/dev/null)
+COMPU_HIP_LIB=$PWD/compu_amd/libcompu_hip_NO_CAND.so rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_encode_noglob_pmc_fetch -o run --output-format csv -- python3 bench.py --workload encode --steps 3 --warmup 1 --no-cpu --extra 0 > /dev/null 2>> gpurun_out/${tag}_bench.log || true
 echo "[profile] source-fetch ablation done"
 hipcc --offload-arch=gfx950 -O3 -o /tmp/fetch_probe tools/exp/fetch_probe.hip 2>/dev/null
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/${tag}_fetch_probe -o run --output-format csv -- /tmp/fetch_probe > gpurun_out/${tag}_fetch_probe.log 2>&1 || true

@@ -54,8 +54,8 @@ out = {"source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate pass
                  f"profiles/{tag}_fetch_probe.txt): FETCH_SIZE reports HALF the bytes of lane-contiguous 16-byte loads (8.0 B per load) and the 64-byte "
                  "request of a scattered 16-byte load as it is (63.9 B per aligned load, 71.4 B at any alignment).  So the LZ77 source fetches of the "
                  "inflate kernel -- FETCH_SIZE of the product minus FETCH_SIZE of the -DCHIP_EXP_NO_GLOB build that leaves them out -- are counted "
-                 "once and the rest of the read side twice; workloads without such an ablation (stored, mixed's zstd half, encode) keep the plain "
-                 "doubling, which overstates their gathers.  Infinity-Cache hits are included in FETCH_SIZE",
+                 "once and the rest of the read side twice; the level-1 encoder's candidate gathers likewise (-DCHIP_EXP_NO_CAND).  Workloads without such "
+                 "an ablation (stored, mixed) keep the plain doubling, which overstates mixed's gathers.  Infinity-Cache hits are included in FETCH_SIZE",
        "build": build,
        "unit": "bytes per launch (65536 units)"}
 KERNELS = {"dynamic": ("inflate_kernel",), "stored": ("inflate_kernel",), "fixed": ("inflate_kernel",), "mixed": ("inflate_kernel", "zstd_kernel"), "encode": ("deflate_kernel",)}
@@ -81,8 +81,10 @@ for wl, kernels in KERNELS.items():
                 w.writerows(allrows)
         scat = None
         try:  # the ablation pass of this workload, when it was taken
-            rr = [r for r in csv.DictReader(open(one(f"{tag}_{wl}_noglob_pmc_fetch/**/*counter_collection.csv"))) if "inflate_kernel" in r["Kernel_Name"] and r["Counter_Name"] == "FETCH_SIZE"]
+            rr = [r for r in csv.DictReader(open(one(f"{tag}_{wl}_noglob_pmc_fetch/**/*counter_collection.csv"))) if any(k in r["Kernel_Name"] for k in kernels) and r["Counter_Name"] == "FETCH_SIZE"]
             rr.sort(key=lambda r: int(r["Dispatch_Id"]))
+            if wl == "encode":
+                rr = rr[:4]
             vals = [float(r["Counter_Value"]) for r in rr[1:4]] or [float(r["Counter_Value"]) for r in rr]
             scat = max(0.0, tot["fetch"] - sum(vals) / len(vals))
         except (SystemExit, ZeroDivisionError):
