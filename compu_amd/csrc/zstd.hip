@@ -213,33 +213,40 @@ struct HufBits {  // backward reader over absolute bit positions, next bit at bi
     uint32_t nextdw;
 };
 
-__device__ __forceinline__ uint32_t huf_load_dw(const Bits &b, int32_t lo, int32_t bit)
+// The dword that holds bits [bit, bit + 32) of the input (bit a multiple of 32), clamped into the buffer.  Nothing is masked: bits
+// outside the stream are whatever lies there -- a prefix code is decided by its own bits, and a symbol that needs more bits than
+// the stream has left is refused by the caller's `r + nb > rend`, so they never decide anything.  (Masking them made every refill
+// wait for its load on the spot: the mask is the load's first use.  A fifth of the kernel's time went there.)
+__device__ __forceinline__ uint32_t huf_load_dw(const Bits &b, int32_t bit)
 {
-    const int32_t i = bit >> 5;
-    if (bit + 32 <= lo || i < 0 || (uint32_t)i >= b.total_dw) return 0u;
-    uint32_t dw = b.g32[i];
-    if (bit < lo) dw &= ~((1u << (lo - bit)) - 1u);
-    return dw;
+    int32_t i = bit >> 5;
+    const int32_t last = (int32_t)b.total_dw - 1;
+    i = i < 0 ? 0 : (i > last ? last : i);
+    return b.g32[i];
 }
 
-__device__ __forceinline__ void huf_bits_init(const Bits &b, HufBits &h, int32_t lo, uint32_t pos)
+__device__ __forceinline__ void huf_bits_init(const Bits &b, HufBits &h, uint32_t pos)
 {
     h.ptr = (int32_t)(pos & ~31u);
     h.cnt = (int32_t)(pos & 31u);
-    h.buf = h.cnt ? (uint64_t)(huf_load_dw(b, lo, h.ptr) & ((1u << h.cnt) - 1u)) << (64 - h.cnt) : 0ull;
-    h.nextdw = huf_load_dw(b, lo, h.ptr - 32);
+    h.buf = h.cnt ? (uint64_t)huf_load_dw(b, h.ptr) << (64 - h.cnt) : 0ull;  // (the bits at and above pos leave through the top)
+    h.nextdw = huf_load_dw(b, h.ptr - 32);
 }
 
-__device__ __forceinline__ uint32_t huf_bits_peek(const Bits &b, HufBits &h, int32_t lo, uint32_t hbits)
+// At least 33 bits in buf afterwards.  Every lane runs it (no branch): a lane that has enough re-requests the dword it already has
+// in flight.  Two symbols (at most 22 bits) may be taken between two refills.
+__device__ __forceinline__ void huf_bits_refill(const Bits &b, HufBits &h)
 {
-    if (h.cnt <= 32) {
-        h.ptr -= 32;
-        h.buf |= (uint64_t)h.nextdw << (32 - h.cnt);
-        h.cnt += 32;
-        h.nextdw = huf_load_dw(b, lo, h.ptr - 32);
-    }
-    return (uint32_t)(h.buf >> (64 - hbits));
+    const bool need = h.cnt <= 32;
+    const uint32_t add = need ? h.nextdw : 0u;
+    h.buf |= (uint64_t)add << ((32 - h.cnt) & 63);
+    const int32_t step = need ? 32 : 0;
+    h.cnt += step;
+    h.ptr -= step;
+    h.nextdw = huf_load_dw(b, h.ptr - 32);
 }
+
+__device__ __forceinline__ uint32_t huf_bits_peek(const HufBits &h, uint32_t hbits) { return (uint32_t)(h.buf >> (64 - hbits)); }
 
 __device__ __forceinline__ void huf_bits_skip(HufBits &h, uint32_t nb)
 {
@@ -269,8 +276,9 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
         bool active = live && r0 < rend;
         if (live && k == 0 && rend == 0) reason = H_END;
         HufBits h;
-        huf_bits_init(b, h, (int32_t)hs.lo, hs.top - (r0 < rend ? r0 : rend));
+        huf_bits_init(b, h, hs.top - (r0 < rend ? r0 : rend));
         while (__any(active)) {
+            huf_bits_refill(b, h);
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const uint32_t rr = active ? r : r0;
@@ -281,25 +289,24 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&rows[(off >> 5) * 64 + g0 + seg], (active && seg == k) ? bit : 0u);
                 const bool joined = active && seg != k && (old & bit);
-                const uint32_t e = L.huf[huf_bits_peek(b, h, (int32_t)hs.lo, hbits)];
+                const uint32_t e = L.huf[huf_bits_peek(h, hbits)];
                 const uint32_t nb = e >> 8;
                 uint32_t st = H_IDLE;
                 st = r + nb > rend ? (uint32_t)H_BAD : st;
                 st = joined ? (uint32_t)H_JOIN : st;
                 const bool go = active && st == H_IDLE;
-                if (active && !go) {
-                    reason = st;
-                    jl = g0 + seg;
-                    rstop = r;
-                }
+                const bool stop = active && !go;  // (selects, not branches: the step is straight-line code)
+                reason = stop ? st : reason;
+                jl = stop ? g0 + seg : jl;
+                rstop = stop ? r : rstop;
+                const uint32_t adv = go ? nb : 0u;
                 nst += go ? 1u : 0u;
-                r += go ? nb : 0u;
-                if (go) huf_bits_skip(h, nb);
+                r += adv;
+                huf_bits_skip(h, adv);
                 active = go && r < rlim && r < rend;
-                if (go && !active) {
-                    reason = r >= rend ? (uint32_t)H_END : (uint32_t)H_LIMIT;
-                    rstop = r;
-                }
+                const bool ran_out = go && !active;
+                reason = ran_out ? (r >= rend ? (uint32_t)H_END : (uint32_t)H_LIMIT) : reason;
+                rstop = ran_out ? r : rstop;
             }
         }
         WSYNC();
@@ -348,12 +355,14 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
         // ---- second pass: the owned symbols, stored
         {
             HufBits h2;
-            huf_bits_init(b, h2, (int32_t)hs.lo, hs.top - (on ? pstart : 0u));
+            huf_bits_init(b, h2, hs.top - (on ? pstart : 0u));
             uint8_t *dst = gout + hs.out + hs.done + first;
             const uint32_t room = hs.want > hs.done + first ? hs.want - (hs.done + first) : 0u;  // never write past the stream's literals
             const uint32_t n = cnt < room ? cnt : room;
 #ifndef CHIP_EXP_NOHUF
-            // four symbols per trip, stored as one dword (at any alignment) instead of four scattered byte stores
+            // four symbols per trip, stored as one dword (at any alignment) instead of four scattered byte stores.  Every lane decodes in
+            // every trip -- a lane past its count reads on into bits that are not its own (clamped into the buffer) and stores nothing --
+            // so the trip is straight-line code with two refills.
             struct __attribute__((packed, aligned(1))) HU32 {
                 uint32_t v;
             };
@@ -361,11 +370,10 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
                 uint32_t word = 0;
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
-                    const uint32_t e = L.huf[huf_bits_peek(b, h2, (int32_t)hs.lo, hbits)];
-                    if (i + t < n) {
-                        word |= (e & 0xffu) << (8 * t);
-                        huf_bits_skip(h2, e >> 8);
-                    }
+                    if ((t & 1u) == 0) huf_bits_refill(b, h2);
+                    const uint32_t e = L.huf[huf_bits_peek(h2, hbits)];
+                    word |= (e & 0xffu) << (8 * t);
+                    huf_bits_skip(h2, e >> 8);
                 }
                 if (i + 4 <= n) {
                     ((HU32 *)(dst + i))->v = word;
