@@ -191,7 +191,10 @@ __device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { retu
 // gives the index of the joined symbol and a prefix sum every piece's place in the literal buffer.  A second
 // pass then decodes exactly the owned symbols again and stores them.  Huffman codes re-synchronise within a few
 // symbols, so the 16 lanes cover ~16 x 224 bits per round with ~50 + 40 serial steps instead of ~570.
-constexpr int HS_BITS = 224;
+#ifndef CHIP_HS_BITS
+#define CHIP_HS_BITS 256
+#endif
+constexpr int HS_BITS = CHIP_HS_BITS;  // a lane's segment; a power of two makes segment and offset a shift and a mask
 #ifndef CHIP_HXT_BITS
 #define CHIP_HXT_BITS 512
 #endif
@@ -282,10 +285,17 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const uint32_t rr = active ? r : r0;
-                // rr / HS_BITS by a 24-bit multiply (full rate; exact for rr < 5461: HS_MAGIC * HS_BITS - 2^20 = 192)
-                constexpr uint32_t HS_MAGIC = ((1u << 20) + HS_BITS - 1) / HS_BITS;
-                static_assert(HS_MAGIC * HS_BITS - (1u << 20) < (1u << 20) / (16u * HS_BITS + HXT_BITS), "segment index by multiplication");
-                const uint32_t seg = __umul24(rr, HS_MAGIC) >> 20, off = rr - __umul24(seg, (uint32_t)HS_BITS);
+                uint32_t seg, off;
+                if constexpr ((HS_BITS & (HS_BITS - 1)) == 0) {
+                    seg = rr / (uint32_t)HS_BITS;
+                    off = rr % (uint32_t)HS_BITS;
+                } else {
+                    // rr / HS_BITS by a 24-bit multiply (full rate; exact while the error term stays under one: checked below)
+                    constexpr uint32_t HS_MAGIC = ((1u << 20) + HS_BITS - 1) / HS_BITS;
+                    static_assert(HS_MAGIC * HS_BITS - (1u << 20) < (1u << 20) / (16u * HS_BITS + HXT_BITS), "segment index by multiplication");
+                    seg = __umul24(rr, HS_MAGIC) >> 20;
+                    off = rr - __umul24(seg, (uint32_t)HS_BITS);
+                }
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&rows[(off >> 5) * 64 + g0 + seg], (active && seg == k) ? bit : 0u);
                 const bool joined = active && seg != k && (old & bit);
