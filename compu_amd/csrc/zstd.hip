@@ -750,7 +750,6 @@ __device__ void xxh_stripes(uint64_t *stage, const uint32_t stage_stripes, const
 {
     constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL;
     auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
-    const XxhView V(p);
     const uint32_t lane = lane_id();
     // The accumulator recurrence acc = rotl(acc + in * P2, 31) * P1 is serial per 8-byte column, but the products
     // in * P2 are not: all 64 lanes form them for up to 128 stripes at a time into `stage` (4 KB of LDS), then lanes 0..3
@@ -759,10 +758,22 @@ __device__ void xxh_stripes(uint64_t *stage, const uint32_t stage_stripes, const
     for (uint32_t s0 = 0; s0 < stripes; s0 += stage_stripes) {
         const uint32_t ns = stripes - s0 < stage_stripes ? stripes - s0 : stage_stripes;
         WSYNC();
+        // one 8-byte load at any alignment per product (gfx950 takes them), all eight of a lane requested before the first is
+        // used: no branch around a load (a lane past the batch's end re-reads its last qword and stores nothing)
+        struct __attribute__((packed, aligned(1))) U64u {
+            uint64_t v;
+        };
+        uint64_t in[8];
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t q = 64u * k + lane;  // qword of the batch: stripe q / 4, column q % 4
-            if (q < 4u * ns) stage[q] = V.rd64(32u * s0 + 8u * q) * P2;
+            const uint32_t qq = q < 4u * ns ? q : 4u * ns - 1u;
+            in[k] = ((const U64u *)(p + 32u * s0 + 8u * qq))->v;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t q = 64u * k + lane;
+            if (q < 4u * ns) stage[q] = in[k] * P2;
         }
         WSYNC();
         if (lane < 4) {
