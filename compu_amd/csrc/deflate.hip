@@ -526,7 +526,9 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             // one unaligned 16-byte load per side: a scattered load costs the L1 a tag lookup per lane and instruction
             // (every lane issues both loads, clamped into the unit, so that waiting for chunk c's bytes leaves chunk
             // c+1's in flight; lanes in the unit's last 15 bytes do not use them)
-#ifdef CHIP_EXP_NO_CAND  // traffic ablation (tools/profile_round.sh): every candidate load reads the lane's own position instead
+#ifdef CHIP_EXP_NO_CAND  // traffic ablation (tools/profile_round.sh): no candidates at all -- every lane's candidate load reads its own
+            c.has = c.has2 = false;  // position, nothing is measured, the unit becomes literals; what is left is the input's own stream
+            c.q = c.q2 = p;
             c.qv = *(const U128u *)(gwide + (p < wide_end ? p : wide_end));
             if constexpr (TWO) c.qv2 = c.qv;
 #else

@@ -619,3 +619,23 @@ def test_concurrent_routed_batches_of_different_sizes_on_one_stream(gpu):
         ol, iu, st = res[k]
         assert gpu.equal(st, single[k][2]) and gpu.equal(ol, single[k][0]) and gpu.equal(iu, single[k][1]), k
         assert gpu.equal(j["out"], j["want"]), k
+
+
+def test_the_two_kernel_pipeline_passes_the_same_parity_tests(gpu):
+    """CHIP_INFLATE_PIPE=1 (read once per process) sends raw-DEFLATE / zlib / gzip batches through tokens_kernel + lz77_kernel with
+    the one-kernel path as the arbiter of everything unusual.  It is not the default -- it measured
+    slower -- but it stays correct: the parity tests of this file that exercise whole batches, damaged and truncated streams, deep
+    codes, small output ranges and multi-block streams run once more in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("CHIP_INFLATE_PIPE") == "1":
+        pytest.skip("already inside the pipeline run")
+    env = dict(os.environ, CHIP_INFLATE_PIPE="1")
+    pick = "small_units or 64k_synthetic or deep_huffman or truncated_corrupt or large_multiblock or compu_status_flag"
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_inflate_gpu.py"), "-x", "-q", "-m", "gpu", "-k", pick, "-p", "no:cacheprovider"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout

@@ -26,7 +26,7 @@ with open(os.path.join(P, f"{tag}_dispatches.csv"), "w") as o:
     o.write("dispatch_index,kernel,duration_ms,workload\n")
     n_inf = 0
     for i, r in enumerate(rows):
-        short = r["Kernel_Name"].split("(")[0]
+        short = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
         wl = ""
         if "inflate_kernel" in short:
             acc = 0
