@@ -117,24 +117,6 @@ __device__ __forceinline__ uint32_t small_mod(uint32_t off, uint32_t d)
     return off - q * d;
 }
 
-// lanes with go: copy their match (at most X_COPY_MAX bytes, not self-overlapping), source and destination in the image
-__device__ __forceinline__ void copy_lanes(lds_u8 *img, uint32_t x, uint32_t src, uint32_t len, bool go)
-{
-    uint32_t rem = go ? len : 0u;
-#pragma unroll
-    for (uint32_t k = 0; k < X_COPY_MAX / 16; k++) {
-        if (k && !__any(rem != 0)) break;
-        if (rem) {
-            const lds_u8 *sp = img + src + 16u * k;
-            const uint32_t v0 = ((const LDS_AS U32u *)sp)->v, v1 = ((const LDS_AS U32u *)(sp + 4))->v;
-            const uint32_t v2 = ((const LDS_AS U32u *)(sp + 8))->v, v3 = ((const LDS_AS U32u *)(sp + 12))->v;
-            const uint32_t n = rem < 16u ? rem : 16u;
-            lds_put(img + x + 16u * k, v0, v1, v2, v3, n);
-            rem -= n;
-        }
-    }
-}
-
 // bits [a, b) of the image's bit map as seen by the word that starts at bit 32 w (a < b)
 __device__ __forceinline__ uint32_t word_mask(uint32_t a, uint32_t b, uint32_t w)
 {

@@ -43,7 +43,7 @@ __device__ __forceinline__ void lane_chunk(uint32_t n, uint32_t &chunk_log2, uin
 // with aligned 16-byte loads, eight bytes per dependent step; the chunks' registers are then combined across lanes.
 // Out of line (three call sites in the inflate kernel; inlined it was a fifth of the kernel's code): the table pointer carries its
 // address space, so its accesses stay LDS accesses.
-__device__ static __attribute__((noinline)) uint32_t wave_crc32(LDS_AS uint32_t *tab, const uint8_t *p_, uint32_t n, uint32_t seed = 0)
+__device__ static __attribute__((noinline, unused)) uint32_t wave_crc32(LDS_AS uint32_t *tab, const uint8_t *p_, uint32_t n, uint32_t seed = 0)
 {
     const uint32_t lane = lane_id();
     const GAS uint8_t *const p = (const GAS uint8_t *)p_;

@@ -905,7 +905,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
 
     int32_t status = ST_RUNNING;
     uint32_t ip = B0;  // absolute byte cursor
-    uint32_t opos = 0, blk0 = 0;  // output cursor; where the block being decoded starts
+    uint32_t opos = 0;  // output cursor
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
     bool has_checksum = false, has_fcs = false;
     uint64_t fcs = 0, window = 0, out_limit = ~0ULL;
@@ -1037,7 +1037,6 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
 
     // ---- blocks (sec. 3.1.1.2) --------------------------------------------------------------------
     while (!blocks_done) {
-        blk0 = opos;
         if (END - ip < 3) ZNEED_INPUT();
         const uint32_t bh = rd32_at(b, ip * 8u) & 0xffffffu;
         const uint32_t last = bh & 1u, type = (bh >> 1) & 3u, bsz = bh >> 3;
@@ -1746,7 +1745,6 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
         }
         save_checkpoint(blocks_done);
     }
-    blk0 = opos;
     if (has_checksum) {
         if (END - ip < 4) ZNEED_INPUT();
         uint32_t want = rd32_at(b, ip * 8u);
