@@ -1,7 +1,7 @@
 """Spill audit of the device code: per kernel the register counts the compiler reports and every spill
 instruction by loop depth.  Runs here (no GPU): compiles each .hip to gfx950 assembly and reads it.
 
-  python tools/spill_audit.py            # table on stdout (markdown)
+  python tools/spill_audit.py [--loops]  # table on stdout (markdown); --loops: where the parked scalar registers are re-read
 
 A loop is a backward branch (s_cbranch_* / s_branch to a label defined above it); an instruction's depth is the number of such
 [label, branch] intervals that contain it.  Spill instructions: scratch_load / scratch_store (lane registers to memory) and
@@ -77,6 +77,22 @@ def audit(body):
             d = sum(1 for a, b in loops if a <= i <= b)
             res.setdefault(kind, {}).setdefault(d, 0)
             res[kind][d] += 1
+    # per loop: parked-register traffic that belongs to the loop itself (not to a loop nested in it)
+    def parked(t):
+        m = re.match(r"v_readlane_b32\s+\S+\s+v(\d+)", t)
+        if m and m.group(1) in park:
+            return "r"
+        m = re.match(r"v_writelane_b32\s+v(\d+)", t)
+        return "w" if m and m.group(1) in park else None
+
+    per_loop = []
+    for a, b in loops:
+        inner = [(c, d) for c, d in loops if a <= c and d <= b and (c, d) != (a, b)]
+        own = [parked(t) for i, t in enumerate(insts[a:b + 1]) if not any(c <= a + i <= d for c, d in inner)]
+        r, w = own.count("r"), own.count("w")
+        if r or w:
+            per_loop.append((b - a + 1, len(inner), r, w))
+    audit.last_loops = per_loop
     return res, len(insts), len(loops)
 
 
@@ -103,15 +119,21 @@ def main():
                     continue
                 res, n, nl = audit(body)
                 short = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("(anonymous namespace)::", "").split("(")[0]
-                rows.append((f, short, meta[name], res, n, nl))
+                rows.append((f, short, meta[name], res, n, nl, list(audit.last_loops)))
 
     def fmt(d):
         return ", ".join(f"depth {k}: {v}" for k, v in sorted(d.items())) if d else "none"
 
     print("| file | kernel | VGPR (+AGPR) | SGPR | lane spills to scratch (vgpr_spill_count) | scalar registers parked in lanes (sgpr_spill_count) | `v_writelane` by loop depth | `v_readlane` by loop depth | scratch by loop depth | instructions / loops |")
     print("|---|---|---|---|---|---|---|---|---|---|")
-    for f, short, m, res, n, nl in rows:
+    for f, short, m, res, n, nl, _ in rows:
         print(f"| `{f}` | `{short}` | {m['vgpr']} (+{m['agpr']}) | {m['sgpr']} | {m['vspill']} | {m['sspill']} | {fmt(res.get('writelane', {}))} | {fmt(res.get('readlane', {}))} | {fmt(res.get('scratch', {}))} | {n} / {nl} |")
+    if "--loops" in sys.argv:
+        print()
+        print("Parked scalar registers by loop (loop length in instructions, loops nested in it, re-reads and writes that belong to the loop itself):")
+        for f, short, m, res, n, nl, per_loop in rows:
+            if per_loop:
+                print(f"* `{short}`: " + "; ".join(f"{ln} instr / {ni} nested: {r} r + {w} w" for ln, ni, r, w in sorted(per_loop)))
 
 
 if __name__ == "__main__":
