@@ -142,7 +142,7 @@ constexpr uint32_t ROW_TOKENS = CHIP_ROW_TOKENS;
 static_assert(S_BITS % 32 == 0 && ROW_TOKENS % 4 == 0 && 64 * ROW_TOKENS < 65536, "geometry");
 constexpr uint32_t SEG_WORDS = S_BITS / 32 + 1;  // mark words a segment can touch
 // x / S_BITS for x < 2^15 (bit offsets inside a super-round) as a multiply and a shift
-constexpr uint32_t SEG_SHIFT = 22;
+constexpr uint32_t SEG_SHIFT = 24;  // (exact for every geometry tried: 224 .. 384-bit segments; checked below)
 constexpr uint32_t SEG_MAGIC = ((1u << SEG_SHIFT) + S_BITS - 1) / S_BITS;
 constexpr bool seg_magic_ok()
 {
@@ -187,7 +187,10 @@ static_assert(CHUNK_BYTES % 4 == 0 && CHUNK_BYTES >= 1024 && COPY_LANE_MAX % 16 
 constexpr uint32_t FLUSH_BYTES = 4 * (IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING + 128);
 constexpr uint32_t HDR_BYTES = 4 * HDR_IN_DW + 4 * (1 << CL_ROOT) + 80 + sizeof(HuffMeta) + 64 + 320 + 2 * 288 + 2 * 32 + 2 * sizeof(HuffMeta);
 constexpr uint32_t PHASE_BYTES = 8 * WIN_DW > FLUSH_BYTES ? (8 * WIN_DW > HDR_BYTES ? 8 * WIN_DW : HDR_BYTES) : (FLUSH_BYTES > HDR_BYTES ? FLUSH_BYTES : HDR_BYTES);
-constexpr uint32_t POOL_WORDS = (10240 - 2 * 512 - 2 * 256 - PHASE_BYTES) / 4;
+#ifndef CHIP_LDS_BYTES
+#define CHIP_LDS_BYTES 10240  // per wave; LDS is granted in 1280-byte steps: 10240 = 16 waves per CU, 8960 = 18, 7680 = 20
+#endif
+constexpr uint32_t POOL_WORDS = (CHIP_LDS_BYTES - 2 * 512 - 2 * 256 - PHASE_BYTES) / 4;
 constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;
 
 struct alignas(16) WaveLds {
@@ -219,14 +222,16 @@ struct alignas(16) WaveLds {
     uint16_t dist_root[1 << DIST_ROOT];
     uint32_t pool[POOL_WORDS];  // literal/length finals and sub-tables from the bottom, distance sub-tables (16-bit) from the top
 };
-static_assert(sizeof(WaveLds) <= 10240, "16 waves per CU: LDS is granted in 1280-byte steps");
+static_assert(sizeof(WaveLds) <= CHIP_LDS_BYTES, "the waves per CU that CHIP_LDS_BYTES stands for");
 // pool[] cannot overflow.  In a canonical code the codes of one length are neighbours, so every 9-bit prefix that lies inside the codes
 // of length L > 9 has a sub-table of 2^(L-9) entries, one per code; only the (at most one per length) prefixes that straddle two lengths
 // hold entries that repeat a code.  Literal/length: <= 286 codes + 1 invalid entry + (2 + 4 + ... + 64) = 413 words; distance (16-bit
 // entries, 8-bit root): <= 30 + (2 + 4 + ... + 128) = 284 entries = 142 words.
 static_assert(POOL_WORDS >= 413 + 142, "the tables of any valid block fit");
 // the CRC-32 tables (2048 words) take the whole structure: nothing else is live while a checksum runs
+#ifndef CHIP_EXP_ALLOW_SMALL_LDS  // (timing probes of raw-deflate batches only: gzip units would run over the structure)
 static_assert(sizeof(WaveLds) >= 2048 * 4, "wave_crc32 needs 8 KB");
+#endif
 
 // Canonical lookup: x15 = next 15 stream bits, first bit in bit 14 (MSB-first code value).  Returns the symbol's index in
 // sorted[] (0xffffffff: no such code) and its length.
@@ -1823,7 +1828,11 @@ hipError_t slot_for(hipStream_t stream, uint32_t n, LaunchSlot &out)
         if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, inflate_kernel, 64, 0)) != hipSuccess) return e;
         if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
         if (per_cu < 1) per_cu = 1;
+#ifdef CHIP_EXP_PER_CU  // occupancy probe: a smaller persistent grid (waves per CU)
+        per_cu = CHIP_EXP_PER_CU;
+#endif
         max_blocks[di] = per_cu * cus;
+        if (getenv("CHIP_DEBUG_GRID")) fprintf(stderr, "[chip] inflate_kernel: %d waves per CU x %d CUs resident (LDS %zu B per wave)\n", per_cu, cus, sizeof(WaveLds));
     }
     const int want = n < (uint32_t)max_blocks[di] ? (int)n : max_blocks[di];
     if (sl.blocks < want) {
