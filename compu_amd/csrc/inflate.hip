@@ -244,6 +244,28 @@ __device__ __forceinline__ uint32_t canon_index(const HuffMeta &H, uint32_t x15,
     return H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l));
 }
 
+// The same with the limits in scalar registers (read once per table build) and the code's length known to lie in [LO, HI]: the root
+// fill knows x15 < limit15[ROOT] (lengths up to ROOT), a sub-table knows x15 >= limit15[ROOT] (lengths above it), so eight or five
+// comparisons against registers stand where fourteen LDS reads and comparisons stood.
+struct CanonLim {
+    uint32_t lim[16];
+};
+__device__ __forceinline__ CanonLim canon_limits(const HuffMeta &H)
+{
+    CanonLim c;
+#pragma unroll
+    for (int j = 0; j < 16; j++) c.lim[j] = rdfirst(H.limit15[j]);
+    return c;
+}
+template <int LO, int HI>
+__device__ __forceinline__ uint32_t canon_index_in(const HuffMeta &H, const CanonLim &c, uint32_t x15, uint32_t &l)
+{
+    l = LO;
+#pragma unroll
+    for (int j = LO; j < HI; j++) l += (x15 >= c.lim[j]) ? 1u : 0u;
+    return H.offs[l] + ((x15 - H.limit15[l - 1]) >> (15 - l));
+}
+
 // Code lengths -> canonical description H and the symbols in canonical order (RFC 1951 sec. 3.2.2), with zlib's acceptance
 // rules.  Wave-cooperative; lens[], count[] live in LDS.  Returns 0, -1 (invalid set) or 1 (empty set); uniform.
 template <typename SortedT, typename MakeT>
@@ -325,7 +347,8 @@ __device__ CHIP_PHASE_FN int build_litlen(WaveLds &L, const uint8_t *lens, int n
     uint16_t *const sorted = L.hdr.lit_sorted;
     const int r = canon_prep(L.hdr.count, lens, n, false, sorted, H, [](uint32_t s, uint32_t) { return (uint16_t)s; });
     if (r != 0) return -1;  // no literal/length code at all cannot be: the end-of-block code exists
-    const uint32_t lim_r = rdfirst(H.limit15[LIT_ROOT]), top = rdfirst(H.limit15[15]);
+    const CanonLim CL = canon_limits(H);
+    const uint32_t lim_r = CL.lim[LIT_ROOT], top = CL.lim[15];
     const uint32_t nshort = rdfirst(H.offs[LIT_ROOT + 1 <= 15 ? LIT_ROOT + 1 : 15]);  // symbols with codes of up to nine bits come first
     const uint32_t nsym = rdfirst(H.offs[15]) + rdfirst(L.hdr.count[15]);
     const uint32_t nfirst = rdfirst(H.maxlen) <= (uint32_t)LIT_ROOT ? nsym : nshort;
@@ -342,7 +365,7 @@ __device__ CHIP_PHASE_FN int build_litlen(WaveLds &L, const uint8_t *lens, int n
         if (x15 >= top) L.lit_root[idx] = (uint16_t)(bad_idx << 5);
         else if (x15 < lim_r) {
             uint32_t l;
-            L.lit_root[idx] = (uint16_t)(canon_index(H, x15, l) << 5);
+            L.lit_root[idx] = (uint16_t)(canon_index_in<1, LIT_ROOT>(H, CL, x15, l) << 5);
         }
     }
     used = nfirst + 1;
@@ -357,7 +380,7 @@ __device__ CHIP_PHASE_FN int build_litlen(WaveLds &L, const uint8_t *lens, int n
             uint32_t sb = 0;
             if (have) {
                 uint32_t l;
-                (void)canon_index(H, xj + P < top ? xj + P - 1 : top - 1, l);
+                (void)canon_index_in<LIT_ROOT + 1, 15>(H, CL, xj + P < top ? xj + P - 1 : top - 1, l);
                 sb = l - LIT_ROOT;
             }
             const uint32_t size = have ? (1u << sb) : 0u;
@@ -370,7 +393,7 @@ __device__ CHIP_PHASE_FN int build_litlen(WaveLds &L, const uint8_t *lens, int n
                     const uint32_t x15 = sb ? xj + ((__brev(t) >> (32 - sb)) << (15 - LIT_ROOT - sb)) : xj;
                     uint32_t l, e = bad_e;
                     if (x15 < top) {
-                        const uint32_t s = sorted[canon_index(H, x15, l)];
+                        const uint32_t s = sorted[canon_index_in<LIT_ROOT + 1, 15>(H, CL, x15, l)];
                         e = make_final(s, l);
                     }
                     L.pool[off + t] = e;
@@ -397,14 +420,15 @@ __device__ CHIP_PHASE_FN int build_dist(WaveLds &L, const uint8_t *lens, int n, 
         WSYNC();
         return 0;
     }
-    const uint32_t lim_r = rdfirst(H.limit15[DIST_ROOT]), top = rdfirst(H.limit15[15]), maxlen = rdfirst(H.maxlen);
+    const CanonLim CL = canon_limits(H);
+    const uint32_t lim_r = CL.lim[DIST_ROOT], top = CL.lim[15], maxlen = rdfirst(H.maxlen);
     uint16_t *const pool16 = (uint16_t *)L.pool;
     for (uint32_t idx = lane; idx < (1u << DIST_ROOT); idx += 64) {
         const uint32_t x15 = __brev(idx) >> 17;
         if (x15 >= top) L.dist_root[idx] = (uint16_t)(maxlen | D_BAD);
         else if (x15 < lim_r) {
             uint32_t l;
-            const uint32_t s = sorted[canon_index(H, x15, l)];
+            const uint32_t s = sorted[canon_index_in<1, DIST_ROOT>(H, CL, x15, l)];
             L.dist_root[idx] = (uint16_t)make_dist16(s, l);
         }
     }
@@ -419,7 +443,7 @@ __device__ CHIP_PHASE_FN int build_dist(WaveLds &L, const uint8_t *lens, int n, 
             uint32_t sb = 0;
             if (have) {
                 uint32_t l;
-                (void)canon_index(H, xj + P < top ? xj + P - 1 : top - 1, l);
+                (void)canon_index_in<DIST_ROOT + 1, 15>(H, CL, xj + P < top ? xj + P - 1 : top - 1, l);
                 sb = l - DIST_ROOT;
             }
             const uint32_t size = have ? (1u << sb) : 0u;
@@ -432,7 +456,7 @@ __device__ CHIP_PHASE_FN int build_dist(WaveLds &L, const uint8_t *lens, int n, 
                     const uint32_t x15 = sb ? xj + ((__brev(t) >> (32 - sb)) << (15 - DIST_ROOT - sb)) : xj;
                     uint32_t l, e = maxlen | D_BAD;
                     if (x15 < top) {
-                        const uint32_t s = sorted[canon_index(H, x15, l)];
+                        const uint32_t s = sorted[canon_index_in<DIST_ROOT + 1, 15>(H, CL, x15, l)];
                         e = make_dist16(s, l);
                     }
                     pool16[base16 + t] = (uint16_t)e;
