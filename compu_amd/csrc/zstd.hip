@@ -210,55 +210,57 @@ struct HufStream {      // per lane: the stream its group of 16 lanes decodes
     uint32_t out;       // index in gout of the stream's first literal
 };
 
-struct HufBits {  // backward reader over absolute bit positions, next bit at bit 63 of buf
-    int32_t ptr, cnt;
-    uint64_t buf;
-    uint32_t nextdw;
+// Backward bit reader of the literal decoder: four symbols (at most 44 bits) are taken from a 64-bit view of the bits below the
+// read position; the view comes out of a 16-byte window that was requested one trip earlier, when the position was known to within
+// those 44 bits -- so a trip never waits for a load it has just issued, and there is no refill bookkeeping (round 4 found the old
+// reader waiting for every refill: first behind a mask, then because a dword requested two symbols earlier had not arrived).
+// Nothing is masked: bits outside the stream are whatever lies there -- a prefix code is decided by its own bits, and a symbol that
+// needs more bits than the stream has left is refused by the caller's `r + nb > rend`, so they never decide anything.
+typedef uint32_t zu32x4 __attribute__((ext_vector_type(4)));
+typedef zu32x4 zu32x4_u __attribute__((aligned(1)));
+struct HufWin {
+    zu32x4 w;        // input bytes [base8 / 8, +16)
+    uint32_t base8;  // absolute bit index of w's first bit
 };
-
-// The dword that holds bits [bit, bit + 32) of the input (bit a multiple of 32), clamped into the buffer.  Nothing is masked: bits
-// outside the stream are whatever lies there -- a prefix code is decided by its own bits, and a symbol that needs more bits than
-// the stream has left is refused by the caller's `r + nb > rend`, so they never decide anything.  (Masking them made every refill
-// wait for its load on the spot: the mask is the load's first use.  A fifth of the kernel's time went there.)
-__device__ __forceinline__ uint32_t huf_load_dw(const Bits &b, int32_t bit)
+// The window for the trip after the one that starts at `pos` (absolute bit index just above the next unread bit): wherever that
+// trip starts, within 44 bits below pos, its 64-bit view lies inside.  The address is clamped into the unit's dwords.
+__device__ __forceinline__ HufWin huf_win_load(const Bits &b, uint32_t pos)
 {
-    int32_t i = bit >> 5;
-    const int32_t last = (int32_t)b.total_dw - 1;
-    i = i < 0 ? 0 : (i > last ? last : i);
-    return b.g32[i];
+    int32_t a = ((int32_t)pos - 108) >> 3;
+    int32_t last = (int32_t)(b.total_dw * 4u) - 16;
+    last = last < 0 ? 0 : last;
+    a = a < 0 ? 0 : (a > last ? last : a);
+    HufWin h;
+    h.w = *(const zu32x4_u *)((const uint8_t *)b.g32 + a);
+    h.base8 = (uint32_t)a * 8u;
+    return h;
+}
+// the 64 bits below pos, the next unread bit at bit 63
+__device__ __forceinline__ uint64_t huf_win_view(const HufWin &h, uint32_t pos)
+{
+    const uint32_t o = (pos - 64u - h.base8) & 63u;
+    const uint32_t t0 = __builtin_amdgcn_alignbit(h.w.y, h.w.x, o), t1 = __builtin_amdgcn_alignbit(h.w.z, h.w.y, o), t2 = __builtin_amdgcn_alignbit(h.w.w, h.w.z, o);
+    const bool up = o >= 32u;
+    return ((uint64_t)(up ? t2 : t1) << 32) | (up ? t1 : t0);
 }
 
-__device__ __forceinline__ void huf_bits_init(const Bits &b, HufBits &h, uint32_t pos)
-{
-    h.ptr = (int32_t)(pos & ~31u);
-    h.cnt = (int32_t)(pos & 31u);
-    h.buf = h.cnt ? (uint64_t)huf_load_dw(b, h.ptr) << (64 - h.cnt) : 0ull;  // (the bits at and above pos leave through the top)
-    h.nextdw = huf_load_dw(b, h.ptr - 32);
-}
-
-// At least 33 bits in buf afterwards.  Every lane runs it (no branch): a lane that has enough re-requests the dword it already has
-// in flight.  Two symbols (at most 22 bits) may be taken between two refills.
-__device__ __forceinline__ void huf_bits_refill(const Bits &b, HufBits &h)
-{
-    const bool need = h.cnt <= 32;
-    const uint32_t add = need ? h.nextdw : 0u;
-    h.buf |= (uint64_t)add << ((32 - h.cnt) & 63);
-    const int32_t step = need ? 32 : 0;
-    h.cnt += step;
-    h.ptr -= step;
-    h.nextdw = huf_load_dw(b, h.ptr - 32);
-}
-
-__device__ __forceinline__ uint32_t huf_bits_peek(const HufBits &h, uint32_t hbits) { return (uint32_t)(h.buf >> (64 - hbits)); }
-
-__device__ __forceinline__ void huf_bits_skip(HufBits &h, uint32_t nb)
-{
-    h.buf <<= nb;
-    h.cnt -= (int32_t)nb;
-}
+// Diagnostic build (-DCHIP_STATS, tools/stats_zstd.py): cycles per phase and trip counts of a frame, 24 words per unit at a.stats.
+#ifdef CHIP_STATS
+#define ZSTAT_PARAM , unsigned long long *zst
+#define ZSTAT_ARG , zst
+#define ZT_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define ZT_END(i, v) (zst[i] += __builtin_readcyclecounter() - (v))
+#define ZC(i, n) (zst[i] += (unsigned long long)(n))
+#else
+#define ZSTAT_PARAM
+#define ZSTAT_ARG
+#define ZT_BEGIN(v)
+#define ZT_END(i, v)
+#define ZC(i, n)
+#endif
 
 // Decodes the four streams described per lane by `hs` into gout.  Returns false on a corrupt stream.
-__device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
+__device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout ZSTAT_PARAM)
 {
     const uint32_t lane = lane_id(), k = lane & 15u, g0 = lane & ~15u;
     const uint32_t hbits = L.huf_bits;
@@ -267,6 +269,7 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
     bool bad = false;
     bool live = true;  // the stream still has symbols to find
     while (__any(live)) {
+        ZC(11, 1);
         const uint32_t rend = hs.top - hs.lo;  // bits left in the stream
 #pragma unroll
         for (int w = 0; w < HROW_WORDS; w++) rows[w * 64 + lane] = 0;
@@ -278,12 +281,14 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
         uint32_t r = r0, nst = 0, reason = H_IDLE, jl = 64, rstop = r0;
         bool active = live && r0 < rend;
         if (live && k == 0 && rend == 0) reason = H_END;
-        HufBits h;
-        huf_bits_init(b, h, hs.top - (r0 < rend ? r0 : rend));
+        HufWin cur = huf_win_load(b, hs.top - (r0 < rend ? r0 : rend));
         while (__any(active)) {
-            huf_bits_refill(b, h);
+            ZC(12, 4);
+            const uint32_t pos_it = hs.top - (r < rend ? r : rend);
+            const HufWin nxt = huf_win_load(b, pos_it);  // (for the next trip: requested now, used then)
+            uint64_t buf = huf_win_view(cur, pos_it);
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
+            for (int u = 0; u < 4; u++) {
                 const uint32_t rr = active ? r : r0;
                 uint32_t seg, off;
                 if constexpr ((HS_BITS & (HS_BITS - 1)) == 0) {
@@ -299,7 +304,7 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
                 const uint32_t bit = 1u << (off & 31u);
                 const uint32_t old = atomicOr(&rows[(off >> 5) * 64 + g0 + seg], (active && seg == k) ? bit : 0u);
                 const bool joined = active && seg != k && (old & bit);
-                const uint32_t e = L.huf[huf_bits_peek(h, hbits)];
+                const uint32_t e = L.huf[(uint32_t)(buf >> (64 - hbits))];
                 const uint32_t nb = e >> 8;
                 uint32_t st = H_IDLE;
                 st = r + nb > rend ? (uint32_t)H_BAD : st;
@@ -312,12 +317,13 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
                 const uint32_t adv = go ? nb : 0u;
                 nst += go ? 1u : 0u;
                 r += adv;
-                huf_bits_skip(h, adv);
+                buf <<= adv;
                 active = go && r < rlim && r < rend;
                 const bool ran_out = go && !active;
                 reason = ran_out ? (r >= rend ? (uint32_t)H_END : (uint32_t)H_LIMIT) : reason;
                 rstop = ran_out ? r : rstop;
             }
+            cur = nxt;
         }
         WSYNC();
         // ---- the true chain of every stream: lane 0 of the group, then whatever it joined, ...
@@ -364,26 +370,29 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
         const uint32_t rz = gather(reason, lz), sz = gather(rstop, lz);
         // ---- second pass: the owned symbols, stored
         {
-            HufBits h2;
-            huf_bits_init(b, h2, hs.top - (on ? pstart : 0u));
+            ZT_BEGIN(zt2);
+            uint32_t pos2 = hs.top - (on ? pstart : 0u);
+            HufWin cur2 = huf_win_load(b, pos2);
             uint8_t *dst = gout + hs.out + hs.done + first;
             const uint32_t room = hs.want > hs.done + first ? hs.want - (hs.done + first) : 0u;  // never write past the stream's literals
             const uint32_t n = cnt < room ? cnt : room;
 #ifndef CHIP_EXP_NOHUF
             // four symbols per trip, stored as one dword (at any alignment) instead of four scattered byte stores.  Every lane decodes in
-            // every trip -- a lane past its count reads on into bits that are not its own (clamped into the buffer) and stores nothing --
-            // so the trip is straight-line code with two refills.
+            // every trip -- a lane past its count reads on into bits that are not its own (the window's address is clamped into the
+            // buffer) and stores nothing -- so the trip is straight-line code.
             struct __attribute__((packed, aligned(1))) HU32 {
                 uint32_t v;
             };
             for (uint32_t i = 0; __any(i < n); i += 4) {
+                const HufWin nxt2 = huf_win_load(b, pos2);
+                uint64_t buf = huf_win_view(cur2, pos2);
                 uint32_t word = 0;
 #pragma unroll
                 for (uint32_t t = 0; t < 4; t++) {
-                    if ((t & 1u) == 0) huf_bits_refill(b, h2);
-                    const uint32_t e = L.huf[huf_bits_peek(h2, hbits)];
+                    const uint32_t e = L.huf[(uint32_t)(buf >> (64 - hbits))];
                     word |= (e & 0xffu) << (8 * t);
-                    huf_bits_skip(h2, e >> 8);
+                    buf <<= e >> 8;
+                    pos2 -= e >> 8;
                 }
                 if (i + 4 <= n) {
                     ((HU32 *)(dst + i))->v = word;
@@ -392,8 +401,10 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout)
                     for (uint32_t t = 0; t < 3; t++)
                         if (i + t < n) dst[i + t] = (uint8_t)(word >> (8 * t));
                 }
+                cur2 = nxt2;
             }
 #endif
+            ZT_END(2, zt2);
         }
 #ifdef CHIP_DEBUG_HUF
         if ((lane & 15) == 0 || lane == 17) printf("l%u live%d rend%u r0%u reason%u rstop%u nst%u nxt%u a0%u on%d cnt%u first%u total%u lz%u rz%u sz%u want%u done%u\n", lane, (int)live, rend, r0, reason, rstop, nst, nxt, a0, (int)on, cnt, first, total, lz, rz, sz, hs.want, hs.done);
@@ -895,6 +906,11 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
     const uint32_t in_len = a.in_len[u];
     uint8_t *gout = a.out_base + a.out_off[u];
     const uint32_t cap = a.out_cap[u];
+#ifdef CHIP_STATS
+    unsigned long long zst_[24] = {};
+    unsigned long long *const zst = zst_;
+    const unsigned long long zt0 = __builtin_readcyclecounter();
+#endif
 
     Bits b;
     const uint32_t mis = (uint32_t)((uintptr_t)gin & 3u);
@@ -1172,7 +1188,10 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     hs.out = myout;
                     WSYNC();
 #ifndef CHIP_EXP_NOLIT  // (ablation: no literal decoding at all)
-                    if (!huf_decode4(L, b, hs, gout)) ZFAIL(ZSTD_E_CORRUPTION);
+                    ZT_BEGIN(zt1);
+                    const bool huf_ok = huf_decode4(L, b, hs, gout ZSTAT_ARG);
+                    ZT_END(1, zt1);
+                    if (!huf_ok) ZFAIL(ZSTD_E_CORRUPTION);
 #endif
                     WSYNC();
                 } else if (lane < streams) {  // a single stream (small literal sections): one lane, symbol by symbol
@@ -1323,6 +1342,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 nseq = 0;
 #endif
                 for (uint32_t i0 = 0; i0 < nseq; i0 += 64) {
+                    ZT_BEGIN(zt4);  // (the whole chunk: what is not chain, phase A or phase B is the parallel part and the placement)
                     const uint32_t cn = nseq - i0 < 64 ? nseq - i0 : 64;
                     uint32_t ll = 0, ml = 0, off = 0;
                     uint32_t dec_bad = 64;  // first sequence of the chunk whose decode is corrupt (verdicts keep stream order)
@@ -1353,6 +1373,8 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     uint32_t my_al = 0, my_ao = 0, my_am = 0, my_el = 0, my_eo = 0, my_em = 0, my_tot = 0;
                     for (;;) {
                         LSYNC();  // the copy phase of the chunk before is done with xpar
+                        ZT_BEGIN(zt3);
+                        ZC(8, 1);
                         __builtin_amdgcn_s_setprio(3);  // a dependent chain: let it go ahead of the other waves' bulk work
                         T = T0;
                         dec_bad = 64;
@@ -1471,6 +1493,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             if (T < Tmin) dec_bad = n_upd;
                         }
                         __builtin_amdgcn_s_setprio(0);
+                        ZT_END(3, zt3);
                         LSYNC();
                         // lane j takes sequence j's states and reads its entries again
                         const bool have = lane < cn && lane < dec_bad;
@@ -1612,6 +1635,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     // (LSYNC in both phases: the steps talk through LDS, and a wave's global stores are seen by its later loads in
                     // program order -- lanes of one wave share the CU's L1 --, so no step waits for its stores to be acknowledged)
                     // ---- phase A: all literal bytes of the chunk (their sources never depend on this chunk) ----
+                    ZT_BEGIN(zt5);
 #ifndef CHIP_EXP_NOEXEC
                     if (LB) {
                         LSYNC();
@@ -1619,6 +1643,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         L.xpar[2 * lane + 1] = lit_before;
                         uint32_t carry = 0;
                         for (uint32_t wb = 0; wb < LB; wb += 256) {
+                            ZC(9, 1);
                             L.xheads[lane] = 0;
                             LSYNC();
                             if (ll && lit_before >= wb && lit_before < wb + 256) ((uint8_t *)L.xheads)[lit_before - wb] = (uint8_t)(lane + 1);
@@ -1657,12 +1682,15 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             LSYNC();
                         }
                     }
+                    ZT_END(5, zt5);
                     // ---- phase B: matches, several per step as long as none reads what the step writes ----------
+                    ZT_BEGIN(zt6);
                     {
                         const uint32_t mbi = wave_incl_scan(ml), mbx = mbi - ml;
                         const uint32_t srcend = mstart - off + (ml < off ? ml : off);
                         uint64_t mm = __ballot(ml != 0);
                         while (mm) {
+                            ZC(10, 1);
                             const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
                             const uint32_t d0 = rdlane(mstart, k0), b0 = rdlane(mbx, k0), l0 = rdlane(ml, k0);
                             if (l0 > 256) {
@@ -1722,6 +1750,8 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         }
                     }
 #endif
+                    ZT_END(6, zt6);
+                    ZT_END(4, zt4);
                     opos += OB;
                     lpos += LB;
                 }
@@ -1756,7 +1786,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
             hash_upto_opos((uint64_t *)L.huf, 128, acc, rel);
             got = xxh_finish(acc, dropped + opos, gout + rel, opos - rel);
         } else {
+            ZT_BEGIN(zt7);
             got = wave_xxh64_low32((uint64_t *)L.huf, gout, opos);  // the Huffman table is dead by now
+            ZT_END(7, zt7);
         }
         if (got != want) ZFAIL(ZSTD_E_CHECKSUM_WRONG);
 #endif
@@ -1781,6 +1813,12 @@ done:
         a.out_len[u] = opos;
         a.in_used[u] = status == CHIP_NEED_INPUT ? in_len : ip - B0;
         a.status[u] = status;
+#ifdef CHIP_STATS
+        if (a.stats) {
+            zst[0] = __builtin_readcyclecounter() - zt0;
+            for (int i = 0; i < 24; i++) a.stats[(size_t)u * 24 + i] = zst[i];
+        }
+#endif
     }
 #undef ZFAIL
 #undef ZNEED_INPUT

@@ -1,4 +1,6 @@
-"""Timing of the zstd kernel alone on synthetic 64 KiB frames: python tools/time_zstd.py [units]"""
+"""Timing of the zstd kernel alone on synthetic 64 KiB frames: python tools/time_zstd.py [units]
+With ZSTATS=1 and a -DCHIP_STATS build (COMPU_HIP_LIB=compu_amd/libcompu_hip_stats.so) it also prints the kernel's own cycle counters
+per frame (phases and trip counts; zstd.hip, ZT_* / ZC)."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -29,6 +31,10 @@ buf = np.zeros((int(lens.astype(np.int64).sum()) + 7) & ~3, np.uint8); buf[: int
 d_out = torch.zeros(n * 65536, dtype=torch.uint8, device=dev)
 args = (100, torch.from_numpy(buf).to(dev), torch.from_numpy(offs).to(dev), torch.from_numpy(lens).to(dev), d_out,
         torch.arange(n, dtype=torch.int64, device=dev) * 65536, torch.full((n,), 65536, dtype=torch.int32, device=dev))
+zstats = None
+if os.environ.get("ZSTATS") == "1":
+    zstats = torch.zeros(n * 24, dtype=torch.int64, device=dev)
+    os.environ["CHIP_STATS_PTR"] = str(zstats.data_ptr())
 for _ in range(2):
     compu_amd.decode_batch(*args)
 torch.cuda.synchronize()
@@ -39,3 +45,12 @@ for _ in range(3):
     ts.append(a.elapsed_time(b))
 ok = bool((st == 2).all()) and torch.equal(d_out, torch.from_numpy(pay).to(dev))
 print(f"{os.path.basename(os.environ.get('COMPU_HIP_LIB','prod'))}: zstd {n} frames, ratio {lens.sum()/(n*65536):.3f}: {min(ts):.3f} ms (correct={ok})")
+if zstats is not None:
+    z = zstats.cpu().numpy().reshape(n, 24).astype(np.float64).mean(axis=0)
+    names = {0: "cycles: whole frame", 1: "cycles: Huffman literals (walk, path, storing pass)", 2: "cycles:   of it the storing pass", 3: "cycles: FSE state chain",
+             4: "cycles: sequence chunks altogether (chain + parallel part + placement + execution)", 5: "cycles: execution phase A (literal bytes)",
+             6: "cycles: execution phase B (matches)", 7: "cycles: XXH64", 8: "trips: chunks of 64 sequences (chain runs)", 9: "trips: phase A steps",
+             10: "trips: phase B steps", 11: "trips: literal rounds", 12: "trips: literal walk steps"}
+    for i in sorted(names):
+        print(f"  {names[i]:85s} {z[i]:12.1f}" + (f"  ({100 * z[i] / z[0]:5.1f} %)" if i and i < 8 and z[0] else ""))
+    print(f"  {'cycles: parallel part + offsets + placement (4 - 3 - 5 - 6)':85s} {z[4] - z[3] - z[5] - z[6]:12.1f}  ({100 * (z[4] - z[3] - z[5] - z[6]) / z[0]:5.1f} %)")
