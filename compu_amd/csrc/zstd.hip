@@ -188,9 +188,10 @@ __device__ __forceinline__ uint32_t byte_at(const Bits &b, uint32_t byte) { retu
 // boundaries inside its own segment in an LDS bitmap and, once below its segment, looks every new position up in
 // the bitmap of the lane that owns the segment it is in; at the first hit the two chains are the same from there
 // on.  The true chain is lane 0's up to its join, then the joined lane's from the join on, and so on; a popcount
-// gives the index of the joined symbol and a prefix sum every piece's place in the literal buffer.  A second
-// pass then decodes exactly the owned symbols again and stores them.  Huffman codes re-synchronise within a few
-// symbols, so the 16 lanes cover ~16 x 224 bits per round with ~50 + 40 serial steps instead of ~570.
+// gives the index of the joined symbol and a prefix sum every piece's place in the literal buffer.  The walk keeps
+// the symbols it decodes in scratch rows and the owned pieces are copied out of them (a second decode of exactly the
+// owned symbols stands in when there is no room for the rows).  Huffman codes re-synchronise within a few symbols, so
+// the 16 lanes cover 16 x 256 bits per round with ~70 serial steps instead of ~740.
 #ifndef CHIP_HS_BITS
 #define CHIP_HS_BITS 256
 #endif
@@ -259,8 +260,16 @@ __device__ __forceinline__ uint64_t huf_win_view(const HufWin &h, uint32_t pos)
 #define ZC(i, n)
 #endif
 
+// The walk keeps what it decodes: every trip (four symbols) leaves one dword per lane in a scratch row -- [trip][lane], so a trip's
+// 64 dwords are one 256-byte store -- and the owned pieces are then copied out of the rows instead of being decoded a second time.
+// The scratch is the part of the frame's own output range that lies between what is written and the parked literals (free while
+// a literal section decodes); without room for it (scr == nullptr), or in a round in which some lane walks more than HSCR_TRIPS trips
+// (codes of a bit or two), the second decode below does the storing.
+constexpr uint32_t HSCR_TRIPS = 32;                           // trips of a round the rows hold (128 symbols per lane)
+constexpr uint32_t HSCR_BYTES = (HSCR_TRIPS + 2) * 256 + 4;   // (+ two rows that the copy's look-ahead may read, + alignment)
+
 // Decodes the four streams described per lane by `hs` into gout.  Returns false on a corrupt stream.
-__device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout ZSTAT_PARAM)
+__device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout, uint32_t *scr ZSTAT_PARAM)
 {
     const uint32_t lane = lane_id(), k = lane & 15u, g0 = lane & ~15u;
     const uint32_t hbits = L.huf_bits;
@@ -282,11 +291,16 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout 
         bool active = live && r0 < rend;
         if (live && k == 0 && rend == 0) reason = H_END;
         HufWin cur = huf_win_load(b, hs.top - (r0 < rend ? r0 : rend));
+        uint32_t trip = 0;  // (uniform)
+        uint32_t pend = 0;  // the trip before's symbols: stored at the top of the next trip, in front of that trip's window request, so
+                            // that the wait for a window never has a younger store in front of it to wait for as well
         while (__any(active)) {
             ZC(12, 4);
+            if (scr && trip && trip <= HSCR_TRIPS) scr[(trip - 1u) * 64u + lane] = pend;
             const uint32_t pos_it = hs.top - (r < rend ? r : rend);
             const HufWin nxt = huf_win_load(b, pos_it);  // (for the next trip: requested now, used then)
             uint64_t buf = huf_win_view(cur, pos_it);
+            uint32_t word = 0;  // the trip's symbols (a lane that stops inside the trip leaves bytes nobody reads)
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 const uint32_t rr = active ? r : r0;
@@ -306,6 +320,7 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout 
                 const bool joined = active && seg != k && (old & bit);
                 const uint32_t e = L.huf[(uint32_t)(buf >> (64 - hbits))];
                 const uint32_t nb = e >> 8;
+                word |= (e & 0xffu) << (8 * u);
                 uint32_t st = H_IDLE;
                 st = r + nb > rend ? (uint32_t)H_BAD : st;
                 st = joined ? (uint32_t)H_JOIN : st;
@@ -323,8 +338,12 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout 
                 reason = ran_out ? (r >= rend ? (uint32_t)H_END : (uint32_t)H_LIMIT) : reason;
                 rstop = ran_out ? r : rstop;
             }
+            pend = word;
+            trip++;
             cur = nxt;
         }
+        if (scr && trip && trip <= HSCR_TRIPS) scr[(trip - 1u) * 64u + lane] = pend;
+        const bool from_rows = scr && trip <= HSCR_TRIPS;
         WSYNC();
         // ---- the true chain of every stream: lane 0 of the group, then whatever it joined, ...
         const uint32_t nxt = reason == H_JOIN ? jl : 64u;
@@ -368,21 +387,48 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout 
         // the stream's chain ends in the lane its last piece lies in
         const uint32_t lz = gather(node, g0 + 15u);
         const uint32_t rz = gather(reason, lz), sz = gather(rstop, lz);
-        // ---- second pass: the owned symbols, stored
+        // ---- the owned symbols, stored: copied out of the walk's rows, or decoded once more
         {
             ZT_BEGIN(zt2);
-            uint32_t pos2 = hs.top - (on ? pstart : 0u);
-            HufWin cur2 = huf_win_load(b, pos2);
             uint8_t *dst = gout + hs.out + hs.done + first;
             const uint32_t room = hs.want > hs.done + first ? hs.want - (hs.done + first) : 0u;  // never write past the stream's literals
             const uint32_t n = cnt < room ? cnt : room;
-#ifndef CHIP_EXP_NOHUF
-            // four symbols per trip, stored as one dword (at any alignment) instead of four scattered byte stores.  Every lane decodes in
-            // every trip -- a lane past its count reads on into bits that are not its own (the window's address is clamped into the
-            // buffer) and stores nothing -- so the trip is straight-line code.
             struct __attribute__((packed, aligned(1))) HU32 {
                 uint32_t v;
             };
+#ifndef CHIP_EXP_NOHUF
+            if (from_rows) {
+                // piece = symbols [a0, a0 + n) of lane `node`'s chain: byte (j & 3) of row word j >> 2.  Eight output dwords per trip
+                // from nine row words requested together; the funnel shift takes out the piece's misalignment in its row.
+                const uint32_t w0 = on ? a0 >> 2 : 0u, sh = (a0 & 3u) * 8u;
+                const uint32_t *const col = scr + (on ? node : lane);
+                for (uint32_t i = 0; __any(i < n); i += 32) {
+                    uint32_t rw[9];
+#pragma unroll
+                    for (uint32_t t = 0; t < 9; t++) {
+                        uint32_t wi = w0 + (i >> 2) + t;
+                        wi = wi < HSCR_TRIPS + 2u ? wi : HSCR_TRIPS + 1u;
+                        rw[t] = col[wi * 64u];
+                    }
+#pragma unroll
+                    for (uint32_t t = 0; t < 8; t++) {
+                        const uint32_t word = __builtin_amdgcn_alignbit(rw[t + 1], rw[t], sh);
+                        const uint32_t at = i + 4u * t;
+                        if (at + 4 <= n) {
+                            ((HU32 *)(dst + at))->v = word;
+                        } else if (at < n) {
+#pragma unroll
+                            for (uint32_t q = 0; q < 3; q++)
+                                if (at + q < n) dst[at + q] = (uint8_t)(word >> (8 * q));
+                        }
+                    }
+                }
+            } else {
+            uint32_t pos2 = hs.top - (on ? pstart : 0u);
+            HufWin cur2 = huf_win_load(b, pos2);
+            // four symbols per trip, stored as one dword (at any alignment) instead of four scattered byte stores.  Every lane decodes in
+            // every trip -- a lane past its count reads on into bits that are not its own (the window's address is clamped into the
+            // buffer) and stores nothing -- so the trip is straight-line code.
             for (uint32_t i = 0; __any(i < n); i += 4) {
                 const HufWin nxt2 = huf_win_load(b, pos2);
                 uint64_t buf = huf_win_view(cur2, pos2);
@@ -402,6 +448,7 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout 
                         if (i + t < n) dst[i + t] = (uint8_t)(word >> (8 * t));
                 }
                 cur2 = nxt2;
+            }
             }
 #endif
             ZT_END(2, zt2);
@@ -757,8 +804,11 @@ struct XxhView {  // aligned dword view of a byte range; reads stay inside dword
     }
 };
 
-__device__ void xxh_stripes(uint64_t *stage, const uint32_t stage_stripes, const uint8_t *p, uint32_t stripes, uint64_t &acc)
+// (out of line; the pointers carry their address spaces, else every access here is a flat one that counts on both wait counters)
+__device__ void xxh_stripes(uint64_t *stage_, const uint32_t stage_stripes, const uint8_t *p_, uint32_t stripes, uint64_t &acc)
 {
+    LDS_AS uint64_t *const stage = (LDS_AS uint64_t *)stage_;
+    const GAS uint8_t *const p = (const GAS uint8_t *)p_;
     constexpr uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL;
     auto rotl = [](uint64_t x, int r) { return (x << r) | (x >> (64 - r)); };
     const uint32_t lane = lane_id();
@@ -779,7 +829,7 @@ __device__ void xxh_stripes(uint64_t *stage, const uint32_t stage_stripes, const
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t q = 64u * k + lane;  // qword of the batch: stripe q / 4, column q % 4
             const uint32_t qq = q < 4u * ns ? q : 4u * ns - 1u;
-            in[k] = ((const U64u *)(p + 32u * s0 + 8u * qq))->v;
+            in[k] = ((const GAS U64u *)(p + 32u * s0 + 8u * qq))->v;
         }
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
@@ -1189,7 +1239,15 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     WSYNC();
 #ifndef CHIP_EXP_NOLIT  // (ablation: no literal decoding at all)
                     ZT_BEGIN(zt1);
-                    const bool huf_ok = huf_decode4(L, b, hs, gout ZSTAT_ARG);
+                    // the walk's scratch rows: the free part of the frame's own output range, if it is large enough (see huf_decode4)
+                    uint32_t *scr = nullptr;
+                    {
+                        // (pointer arithmetic on gout, not an integer round trip: the accesses stay global_*, a flat store would also
+                        // count on the LDS counter and every LDS wait of the walk would wait for it)
+                        const uint32_t pad = (4u - (uint32_t)((uintptr_t)(gout + opos) & 3u)) & 3u;
+                        if ((uint64_t)opos + pad + HSCR_BYTES <= lit_out) scr = (uint32_t *)(gout + opos + pad);
+                    }
+                    const bool huf_ok = huf_decode4(L, b, hs, gout, scr ZSTAT_ARG);
                     ZT_END(1, zt1);
                     if (!huf_ok) ZFAIL(ZSTD_E_CORRUPTION);
 #endif
