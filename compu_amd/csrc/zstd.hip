@@ -688,18 +688,37 @@ __device__ int huf_build(ZLds &L, int n)
             before += (uint32_t)__popcll(m);
         }
     }
-    // fill: one symbol after the other, the 64 lanes spread over the symbol's 2^(weight-1) entries
+    // fill, entry by entry (32 per lane): the table holds the symbols by rising weight, a symbol of weight wt in 2^(wt-1) neighbouring
+    // entries.  An entry finds its weight class from the classes' first positions, its rank in the class from its distance to that
+    // position, and the symbol from the list of symbols in (weight, symbol) order that is written first (over the weights, which are
+    // in registers by now).  (Symbol by symbol with the lanes spread over a symbol's entries -- most symbols have one to four -- this
+    // was 200 serial steps per table: a twelfth of the kernel.)
+    uint32_t firstw[12];  // symbols of lower weights
+    {
+        uint32_t acc = 0;
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-        uint64_t todo = __ballot(w[c] != 0);
-        while (todo) {
-            const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
-            todo &= todo - 1;
-            const uint32_t wj = rdlane(w[c], j), pj = rdlane(pos[c], j);
-            const uint32_t len = 1u << (wj - 1);
-            const uint16_t val = (uint16_t)((64u * c + j) | (((uint32_t)maxbits + 1u - wj) << 8));
-            for (uint32_t k = lane; k < len; k += 64) L.huf[pj + k] = val;
+        for (uint32_t wt = 1; wt <= 11; wt++) {
+            firstw[wt] = acc;
+            acc += cntw[wt];
         }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (w[c]) L.weights[firstw[w[c]] + ((pos[c] - basew[w[c]]) >> (w[c] - 1u))] = (uint8_t)(64 * c + (int)lane);
+    WSYNC();
+    const uint32_t size = 1u << maxbits;
+    for (uint32_t x = lane; x < size; x += 64) {
+        uint32_t wt = 1;
+#pragma unroll
+        for (uint32_t t = 2; t <= 11; t++) wt += (x >= basew[t]) ? 1u : 0u;  // (classes without symbols share their successor's position)
+        uint32_t bw = 0, fw = 0;
+#pragma unroll
+        for (uint32_t t = 1; t <= 11; t++) {
+            bw = wt == t ? basew[t] : bw;
+            fw = wt == t ? firstw[t] : fw;
+        }
+        const uint32_t sym = L.weights[fw + ((x - bw) >> (wt - 1u))];
+        L.huf[x] = (uint16_t)(sym | (((uint32_t)maxbits + 1u - wt) << 8));
     }
     if (lane == 0) {
         L.huf_bits = (uint32_t)maxbits;
@@ -710,7 +729,7 @@ __device__ int huf_build(ZLds &L, int n)
 }
 
 // Huffman tree description at absolute byte p0 (<= n bytes): returns bytes consumed or -1.
-__device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
+__device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n ZSTAT_PARAM)
 {
     if (n < 1) return -1;
     const uint32_t hb = byte_at(b, p0);
@@ -729,9 +748,12 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
         used = 1 + hb;
         if (hb == 0 || used > n) return -1;
         int al, nsym;
+        ZT_BEGIN(zt15);
         int c = fse_read_ncount(L, b, p0 + 1, hb, 6, 12, al, nsym);
         if (c < 0) return -1;
         if (fse_build(L, view(L.wt), nsym, al)) return -1;
+        ZT_END(15, zt15);
+        ZT_BEGIN(zt16);
         BackBits s;
         if (!bb_init(b, s, p0 + 1 + (uint32_t)c, hb - (uint32_t)c)) return -1;
         // the weight stream is at most 127 bytes: lane i keeps its i-th dword, so the (serial, two-state) FSE decode below
@@ -739,46 +761,47 @@ __device__ int huf_read(ZLds &L, const Bits &b, uint32_t p0, uint32_t n)
         const uint32_t d0 = rdfirst(s.lo >> 5), lo0 = rdfirst(s.lo);
         const uint32_t mydw = d0 + lane_id() < b.total_dw ? b.g32[d0 + lane_id()] : 0u;
         int32_t avail = (int32_t)rdfirst((uint32_t)s.avail);
+        // Everything in the loop below is the same in every lane and is written so that it stays on the scalar unit: the stream's
+        // dwords and the table's entries are read with readlane, the shifts are 64-bit scalar shifts, every lane stores the (same)
+        // weight.  (With a vector funnel shift in it the compiler kept the states in vector registers and paid a readfirstlane, an
+        // exec-mask region and hazard no-ops per weight: 84 instructions per weight on a serial chain.)
         auto take = [&](uint32_t nbits) -> uint32_t {  // next nbits (<= 24) of the stream; bits below its start read as zero
             uint32_t v = 0;
             if (nbits != 0 && avail > 0) {
                 const uint32_t have = (uint32_t)avail >= nbits ? nbits : (uint32_t)avail;
                 const uint32_t pos = lo0 + (uint32_t)avail - have;
-                const uint32_t i = rdfirst((pos >> 5) - d0) & 63u;
-                const uint32_t w0 = rdlane(mydw, i), w1 = rdlane(mydw, (i + 1u) & 63u);
-                v = (__builtin_amdgcn_alignbit(w1, w0, pos & 31u) & ((1u << have) - 1u)) << (nbits - have);
+                const uint32_t i = ((pos >> 5) - d0) & 63u;
+                const uint64_t ww = ((uint64_t)rdlane(mydw, (i + 1u) & 63u) << 32) | rdlane(mydw, i);
+                v = ((uint32_t)(ww >> (pos & 31u)) & ((1u << have) - 1u)) << (nbits - have);
             }
             avail -= (int32_t)nbits;
             return v;
         };
-        uint32_t s1 = take((uint32_t)al), s2 = take((uint32_t)al);
+        const uint32_t al_u = rdfirst((uint32_t)al);
+        uint32_t sa = take(al_u), sb = take(al_u);
         if (avail < 0) return -1;
-        const bool w = lane_id() == 0;
-        for (;;) {
+        // the weights' table has at most 64 states: lane i keeps entry i, a state's entry is a readlane away
+        const uint32_t mye = lane_id() < (1u << al_u) ? L.wt.e[lane_id()] : 0u;
+        for (;;) {  // the two states take turns: sa decodes, sb is the other one
             if (nw > 253) return -1;
-            uint32_t e1 = rdfirst(L.wt.e[s1]);
-            if (w) L.weights[nw] = (uint8_t)(e1 & 63u);
+            const uint32_t e = rdlane(mye, sa & 63u);
+            L.weights[nw] = (uint8_t)(e & 63u);
             nw++;
-            s1 = (e1 >> 16) + take((e1 >> 6) & 15u);
+            const uint32_t nxt = (e >> 16) + take((e >> 6) & 15u);
             if (avail < 0) {
-                if (w) L.weights[nw] = (uint8_t)(L.wt.e[s2] & 63u);
+                L.weights[nw] = (uint8_t)(rdlane(mye, sb & 63u) & 63u);
                 nw++;
                 break;
             }
-            if (nw > 253) return -1;
-            uint32_t e2 = rdfirst(L.wt.e[s2]);
-            if (w) L.weights[nw] = (uint8_t)(e2 & 63u);
-            nw++;
-            s2 = (e2 >> 16) + take((e2 >> 6) & 15u);
-            if (avail < 0) {
-                if (w) L.weights[nw] = (uint8_t)(L.wt.e[s1] & 63u);
-                nw++;
-                break;
-            }
+            sa = sb;
+            sb = nxt;
         }
+        ZT_END(16, zt16);
     }
     if (nw > 255) return -1;
+    ZT_BEGIN(zt17);
     if (huf_build(L, nw)) return -1;
+    ZT_END(17, zt17);
     return (int)used;
 }
 
@@ -1191,7 +1214,9 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 if (comp > left) ZFAIL(ZSTD_E_CORRUPTION);
                 uint32_t lp = p, lleft = comp;
                 if (ltype == 2) {
-                    int c = huf_read(L, b, lp, lleft);
+                    ZT_BEGIN(zt13);
+                    int c = huf_read(L, b, lp, lleft ZSTAT_ARG);
+                    ZT_END(13, zt13);
                     if (c < 0) ZFAIL(ZSTD_E_CORRUPTION);
                     lp += (uint32_t)c;
                     lleft -= (uint32_t)c;
@@ -1341,6 +1366,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                 p += 1;
                 left -= 1;
                 if (modes & 3u) ZFAIL(ZSTD_E_CORRUPTION);
+                ZT_BEGIN(zt14);
                 for (int k = 0; k < 3; k++) {
                     const FseView t = k == 0 ? view(L.ll) : k == 1 ? view(L.of) : view(L.ml);
                     const int maxal = k == 1 ? 8 : 9, maxsym = k == 0 ? 35 : k == 1 ? 31 : 52;
@@ -1383,6 +1409,7 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                     }
                 }
                 WSYNC();
+                ZT_END(14, zt14);
                 BackBits s0;
                 if (!bb_init(b, s0, p, left)) ZFAIL(ZSTD_E_CORRUPTION);
                 SeqBits s;

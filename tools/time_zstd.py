@@ -50,7 +50,9 @@ if zstats is not None:
     names = {0: "cycles: whole frame", 1: "cycles: Huffman literals (walk, path, storing pass)", 2: "cycles:   of it the storing pass", 3: "cycles: FSE state chain",
              4: "cycles: sequence chunks altogether (chain + parallel part + placement + execution)", 5: "cycles: execution phase A (literal bytes)",
              6: "cycles: execution phase B (matches)", 7: "cycles: XXH64", 8: "trips: chunks of 64 sequences (chain runs)", 9: "trips: phase A steps",
-             10: "trips: phase B steps", 11: "trips: literal rounds", 12: "trips: literal walk steps"}
+             10: "trips: phase B steps", 11: "trips: literal rounds", 12: "trips: literal walk steps",
+             13: "cycles: Huffman table (weights, their FSE table, code table)", 14: "cycles: the three sequence tables (descriptions, builds, re-coding)",
+             15: "cycles:   Huffman: description and FSE table of the weights", 16: "cycles:   Huffman: the weights' two-state decode", 17: "cycles:   Huffman: code table from the weights"}
     for i in sorted(names):
-        print(f"  {names[i]:85s} {z[i]:12.1f}" + (f"  ({100 * z[i] / z[0]:5.1f} %)" if i and i < 8 and z[0] else ""))
+        print(f"  {names[i]:85s} {z[i]:12.1f}" + (f"  ({100 * z[i] / z[0]:5.1f} %)" if i and (i < 8 or i >= 13) and z[0] else ""))
     print(f"  {'cycles: parallel part + offsets + placement (4 - 3 - 5 - 6)':85s} {z[4] - z[3] - z[5] - z[6]:12.1f}  ({100 * (z[4] - z[3] - z[5] - z[6]) / z[0]:5.1f} %)")
