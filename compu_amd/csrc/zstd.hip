@@ -482,16 +482,18 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout,
 __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, int max_al, int max_sym, int &al_out, int &nsym_out)
 {
     if (n < 1) return -1;
-    uint32_t bit = p0 * 8u;
-    const uint32_t endbit = (p0 + n) * 8u;
-    // the description is a few dozen bytes: lane i keeps dword i of it, bits are then read with readlane instead of one
-    // memory round trip per symbol (everything here is wave-uniform)
-    const uint32_t d0 = rdfirst(bit >> 5);
+    uint32_t bit = rdfirst(p0 * 8u);
+    const uint32_t endbit = rdfirst((p0 + n) * 8u);
+    // The description is a few dozen bytes (at most 53 counts of at most ten bits, plus zero-run flags: under 80): lane i keeps dword i
+    // of it and bits are read with readlane.  Everything here is the same in every lane and is kept on the scalar unit: a 64-bit
+    // scalar shift cuts the bits (a vector funnel shift made the compiler hold the counts in vector registers, with an exec-mask region
+    // per decision: 200 instructions per symbol), every lane stores the (same) count.
+    const uint32_t d0 = bit >> 5;
     const uint32_t mydw = d0 + lane_id() < b.total_dw ? b.g32[d0 + lane_id()] : 0u;
     auto rdw = [&](uint32_t at) -> uint32_t {
-        const uint32_t i = rdfirst((at >> 5) - d0);
-        if (i < 63u) return __builtin_amdgcn_alignbit(rdlane(mydw, i + 1u), rdlane(mydw, i), at & 31u);
-        return rd32_at(b, at);
+        const uint32_t i = ((at >> 5) - d0) & 63u;
+        const uint64_t ww = ((uint64_t)rdlane(mydw, (i + 1u) & 63u) << 32) | rdlane(mydw, i);
+        return (uint32_t)(ww >> (at & 31u));
     };
     int al = (int)(rdw(bit) & 15u) + 5;
     bit += 4;
@@ -503,13 +505,13 @@ __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, 
             while ((rdw(bit) & 3u) == 3u) {
                 n0 += 3;
                 bit += 2;
-                if (bit > endbit + 7) return -1;
+                if (bit > endbit + 7 || bit - 32u * d0 > 61u * 32u) return -1;
             }
             n0 += (int)(rdw(bit) & 3u);
             bit += 2;
             if (n0 > max_sym + 1) return -1;
             while (sym < n0) {
-                if (lane_id() == 0) L.norm[sym] = 0;
+                L.norm[sym] = 0;
                 sym++;
             }
             if (sym > max_sym) break;
@@ -526,14 +528,14 @@ __device__ int fse_read_ncount(ZLds &L, const Bits &b, uint32_t p0, uint32_t n, 
         }
         count--;
         remaining -= count < 0 ? -count : count;
-        if (lane_id() == 0) L.norm[sym] = (int16_t)count;
+        L.norm[sym] = (int16_t)count;
         sym++;
         prev0 = !count;
         while (remaining < threshold) {
             nbits--;
             threshold >>= 1;
         }
-        if (bit > endbit + 7) return -1;
+        if (bit > endbit + 7 || bit - 32u * d0 > 61u * 32u) return -1;  // (the second: past the staged dwords; no valid description gets there)
     }
     if (remaining != 1 || sym > max_sym + 1) return -1;
     al_out = al;
