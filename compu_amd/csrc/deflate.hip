@@ -491,37 +491,32 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                 c.v = p < n ? __builtin_amdgcn_alignbit(i + 1 < total_dw ? vd1 : 0u, i < total_dw ? vd0 : 0u, (off & 3u) * 8u) : 0u;
             }
             fetch_v(p + 64u);
-            uint32_t h = 0, old0 = 0;
-            c.has = c.has2 = false;
-            c.q = c.q2 = p;
-            if (valid4) {
-                h = (c.v * 2654435761u) >> (32 - HASH_BITS);
-                old0 = L.table[h];
-                const uint32_t dist = (p - old0) & 0xffffu;  // the nearest earlier position with the slot's low 16 bits
-                if (dist - 1u < MAX_DIST && dist <= p) {
-                    c.has = true;
-                    c.q = p - dist;
-                }
-                if constexpr (TWO) {
-                    const uint32_t dist2 = (p - L.table[(1u << HASH_BITS) + h]) & 0xffffu;
-                    if (dist2 - 1u < MAX_DIST && dist2 <= p && dist2 != dist) {
-                        c.has2 = true;
-                        c.q2 = p - dist2;
-                    }
-                }
-                // Z_RLE: the only candidate is the byte before (distance 1); Z_HUFFMAN_ONLY: none
-                if (rle) {
-                    c.has = p > 0;
-                    c.q = p > 0 ? p - 1 : p;
-                }
-                if (no_match) {
-                    c.has = false;
-                    c.q = p;
-                }
-                if (rle || no_match) {
-                    c.has2 = false;
-                    c.q2 = p;
-                }
+            // (selects, not an `if (valid4)` region: every exec-mask region costs the scalar unit three instructions and a branch, and this
+            // loop has a dozen of them per chunk; a lane without four bytes hashes the zero it holds and reads a slot it ignores)
+            const uint32_t h = (c.v * 2654435761u) >> (32 - HASH_BITS);
+            const uint32_t old0 = L.table[h];
+            const uint32_t dist = (p - old0) & 0xffffu;  // the nearest earlier position with the slot's low 16 bits
+            c.has = valid4 && dist - 1u < MAX_DIST && dist <= p;
+            c.q = c.has ? p - dist : p;
+            c.has2 = false;
+            c.q2 = p;
+            if constexpr (TWO) {
+                const uint32_t dist2 = (p - L.table[(1u << HASH_BITS) + h]) & 0xffffu;
+                c.has2 = valid4 && dist2 - 1u < MAX_DIST && dist2 <= p && dist2 != dist;
+                c.q2 = c.has2 ? p - dist2 : p;
+            }
+            // Z_RLE: the only candidate is the byte before (distance 1); Z_HUFFMAN_ONLY: none
+            if (rle) {
+                c.has = valid4 && p > 0;
+                c.q = c.has ? p - 1 : p;
+            }
+            if (no_match) {
+                c.has = false;
+                c.q = p;
+            }
+            if (rle || no_match) {
+                c.has2 = false;
+                c.q2 = p;
             }
             // one unaligned 16-byte load per side: a scattered load costs the L1 a tag lookup per lane and instruction
             // (every lane issues both loads, clamped into the unit, so that waiting for chunk c's bytes leaves chunk
@@ -570,46 +565,40 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             uint32_t mlen = 0, mdist = 0;
             const uint32_t v = cur.v;
             // common prefix of the position with a candidate (its first 16 bytes in qv), 0 if under MIN_MATCH
-            auto measure = [&](const uint32_t q, const U128u &qv) __attribute__((always_inline)) {
+            auto measure = [&](const bool has, const uint32_t q, const U128u &qv) __attribute__((always_inline)) {
                 const uint32_t lim = n - p < MAX_MATCH ? n - p : MAX_MATCH;
-                // the first 16 bytes of both sides arrived together: most candidates are decided right here
-                uint32_t k = 0;
-                bool diff = false;
-                if (p + 16 <= n) {
-                    k = first_diff16(qv, cur.pv);
-                    diff = k < 16;
-                }
-                if (!diff) {
-                    while (k < lim) {
-                        if (p + k + 16 <= n) {
-                            const uint32_t d = first_diff16(*(const U128u *)(gin + q + k), *(const U128u *)(gin + p + k));
-                            k += d;
-                            if (d < 16) break;
-                        } else {
-                            uint32_t x = ld32(g32, total_dw, mis + q + k) ^ ld32(g32, total_dw, mis + p + k);
-                            if (x) {
-                                k += ((uint32_t)__ffs((int)x) - 1u) >> 3;
-                                break;
+                // the first 16 bytes of both sides arrived together: most candidates are decided right here, without a branch; the
+                // loop below runs only when some lane's candidate is not (a uniform test), and only for those lanes
+                const bool wide = p + 16 <= n;
+                uint32_t k = wide ? first_diff16(qv, cur.pv) : 0u;
+                const bool more = has && (!wide || k >= 16u) && k < lim;
+                if (__any(more)) {
+                    if (more) {
+                        while (k < lim) {
+                            if (p + k + 16 <= n) {
+                                const uint32_t d = first_diff16(*(const U128u *)(gin + q + k), *(const U128u *)(gin + p + k));
+                                k += d;
+                                if (d < 16) break;
+                            } else {
+                                uint32_t x = ld32(g32, total_dw, mis + q + k) ^ ld32(g32, total_dw, mis + p + k);
+                                if (x) {
+                                    k += ((uint32_t)__ffs((int)x) - 1u) >> 3;
+                                    break;
+                                }
+                                k += 4;
                             }
-                            k += 4;
                         }
                     }
                 }
                 if (k > lim) k = lim;
-                return k >= MIN_MATCH ? k : 0u;
+                return has && k >= MIN_MATCH ? k : 0u;
             };
-            if (cur.has) {
-                mlen = measure(cur.q, cur.qv);
-                mdist = mlen ? p - cur.q : 0u;
-            }
+            mlen = measure(cur.has, cur.q, cur.qv);
+            mdist = mlen ? p - cur.q : 0u;
             if constexpr (TWO) {
-                if (cur.has2) {  // the older position wins only with a longer match
-                    const uint32_t k2 = measure(cur.q2, cur.qv2);
-                    if (k2 > mlen) {
-                        mlen = k2;
-                        mdist = p - cur.q2;
-                    }
-                }
+                const uint32_t k2 = measure(cur.has2, cur.q2, cur.qv2);  // the older position wins only with a longer match
+                mdist = k2 > mlen ? p - cur.q2 : mdist;
+                mlen = k2 > mlen ? k2 : mlen;
             }
             // greedy choice, left to right over the chunk: jump from selected match to selected match (a scalar
             // step per chosen match, not per position); everything in between is a literal
@@ -691,27 +680,30 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             skip = pos > 64 ? pos - 64 : 0;
             const bool mine = (sel >> lane) & 1ull;
             if constexpr (!DYN) {
-                uint32_t nb = 0, bits = 0;
-                if (mine) {
-                    // literal and match both computed, one kept (no divergent branches)
+                // literal and match both computed by every lane, one kept, a lane that emits nothing adds zero bits: no exec-mask regions
+                uint32_t nb, bits;
+                {
+                    const bool is_match = mlen >= MIN_MATCH;
                     const uint32_t lit = v & 0xffu, lnb = lit < 144 ? 8u : 9u;
                     const uint32_t lbits = rev_bits(lit < 144 ? 0x30u + lit : 0x100u + lit, 9) >> (9u - lnb);
-                    const uint32_t e = L.lentab[mlen >= MIN_MATCH ? mlen - 3u : 0u];
+                    const uint32_t e = L.lentab[is_match ? mlen - 3u : 0u];
                     uint32_t dc, dext, dxv;
-                    dist_parts(mlen >= MIN_MATCH ? mdist : 1u, dc, dext, dxv);
+                    dist_parts(is_match ? mdist : 1u, dc, dext, dxv);
                     uint32_t mnb = e >> 16, mbits = e & 0xffffu;
                     mbits |= rev_bits(dc, 5) << mnb;
                     mnb += 5;
                     mbits |= dxv << mnb;
                     mnb += dext;
-                    bits = mlen >= MIN_MATCH ? mbits : lbits;
-                    nb = mlen >= MIN_MATCH ? mnb : lnb;
+                    bits = is_match ? mbits : lbits;
+                    nb = is_match ? mnb : lnb;
+                    nb = mine ? nb : 0u;
+                    bits = mine ? bits : 0u;
                 }
                 const uint32_t incl = wave_incl_scan(nb);
-                if (mine) {
-                    uint32_t at = nbits + incl - nb, w = at >> 5, sh = at & 31u;
-                    atomicOr(&L.obuf[w], bits << sh);
-                    if (sh && (nb + sh > 32)) atomicOr(&L.obuf[w + 1], bits >> (32 - sh));
+                {
+                    const uint32_t at = nbits + incl - nb, w = at >> 5, sh = at & 31u;
+                    atomicOr(&L.obuf[w], bits << sh);  // (zero for a lane that emits nothing; its word lies inside the buffer)
+                    atomicOr(&L.obuf[w + 1], (sh && nb + sh > 32) ? bits >> (32 - sh) : 0u);
                 }
                 nbits += rdlane(incl, 63);
                 if (nbits > (uint32_t)(OUT_DW - 64) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
