@@ -1157,6 +1157,9 @@ int chip_encode_batch_ex(int format, int level, int strategy, size_t n, const vo
     a.resume = nullptr;
     a.sel = nullptr;
     a.sel_n = nullptr;
+#ifdef CHIP_STATS
+    a.stats = (unsigned long long *)getenv("CHIP_STATS_PTR") ? (unsigned long long *)strtoull(getenv("CHIP_STATS_PTR"), nullptr, 0) : nullptr;
+#endif
     hipError_t e = launch_deflate_l1(a, level, 7u | ((uint32_t)strategy << 8), format == CHIP_FMT_ZLIB ? 1u : 0u, 0, nullptr, (hipStream_t)stream);
     return e == hipSuccess ? CHIP_OK : CHIP_E_LAUNCH;
 }

@@ -396,10 +396,25 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 // One unit (one wave).  DYN = false: level 0/1 and Z_FIXED, one fixed-Huffman block or stored blocks (LDS = ELds).
 // DYN = true: levels 2..9, the chunks' tokens go to tokbuf (TOK_BLOCK words of HBM scratch of this wave) and every
 // TOK_BLOCK-64.. tokens a block is written with the cheapest of dynamic / fixed / stored (LDS = DLds).
+// Diagnostic build (-DCHIP_STATS, ESTATS=1 tools/time_encode.py): cycles per phase of the level-1 chunk loop, 24 words per unit.
+#ifdef CHIP_STATS
+#define ET_BEGIN(v) const unsigned long long v = __builtin_readcyclecounter()
+#define ET_END(i, v) (est[i] += __builtin_readcyclecounter() - (v))
+#define EC(i, n) (est[i] += (unsigned long long)(n))
+#else
+#define ET_BEGIN(v)
+#define ET_END(i, v)
+#define EC(i, n)
+#endif
+
 template <bool DYN, class LDS>
 __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, LDS &L, uint32_t *tokbuf)
 {
     const uint32_t lane = lane_id();
+#ifdef CHIP_STATS
+    unsigned long long est[24] = {};
+    const unsigned long long et0 = __builtin_readcyclecounter();
+#endif
     const uint8_t *gin = a.b.in_base + a.b.in_off[u];
     const uint32_t n = a.b.in_len[u];
     uint8_t *gout = a.b.out_base + a.b.out_off[u];
@@ -560,7 +575,11 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
         };
         // one chunk: look the next one up (its loads fly while this one is worked on), measure, choose, emit
         auto step = [&](Cand &cur, Cand &nxt, const uint32_t base) __attribute__((always_inline)) {
+            ET_BEGIN(et1);
             lookup(nxt, base + 64);  // past the end this is an empty chunk: same loads, nothing looked up
+            ET_END(1, et1);
+            EC(8, 1);
+            ET_BEGIN(et2);
             const uint32_t p = base + lane;
             uint32_t mlen = 0, mdist = 0;
             const uint32_t v = cur.v;
@@ -604,7 +623,10 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
             // step per chosen match, not per position); everything in between is a literal
             const uint32_t lim64 = n - base < 64 ? n - base : 64;
             const uint64_t limmask = lim64 >= 64 ? ~0ull : ((1ull << lim64) - 1ull);
+            ET_END(2, et2);
+            ET_BEGIN(et3);
             const uint64_t cand = __ballot(mlen >= MIN_MATCH) & limmask;
+            EC(9, __popcll(cand));
             uint64_t covered = 0;  // positions inside a chosen match (its start excluded)
             uint64_t deferred = 0;  // lazy levels: match candidates that gave way to the next position and became literals
             uint32_t pos = rdfirst(skip);
@@ -676,7 +698,10 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     : "scc");
                 }
             }
+            ET_END(3, et3);
+            ET_BEGIN(et4);
             const uint64_t sel = skip < 64 ? limmask & ~covered & (~0ull << skip) : 0ull;
+            EC(10, __popcll(sel));
             skip = pos > 64 ? pos - 64 : 0;
             const bool mine = (sel >> lane) & 1ull;
             if constexpr (!DYN) {
@@ -706,7 +731,10 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
                     atomicOr(&L.obuf[w + 1], (sh && nb + sh > 32) ? bits >> (32 - sh) : 0u);
                 }
                 nbits += rdlane(incl, 63);
+                ET_END(4, et4);
+                ET_BEGIN(et5);
                 if (nbits > (uint32_t)(OUT_DW - 64) * 32u) obytes += flush_bits(L, gout, cap, obytes, nbits, false);
+                ET_END(5, et5);
             } else {
                 // tokens to the scratch in order, symbol counts to LDS
                 if (mine) {
@@ -985,6 +1013,12 @@ __device__ __forceinline__ void encode_unit(const EncArgs &a, const uint32_t u, 
     if (lane == 0) {
         a.b.out_len[u] = obytes <= cap ? obytes : cap;
         a.b.status[u] = obytes <= cap ? CHIP_ENC_FINISHED : CHIP_ENC_NEED_OUTPUT;
+#ifdef CHIP_STATS
+        if (a.b.stats) {
+            est[0] = __builtin_readcyclecounter() - et0;
+            for (int i = 0; i < 24; i++) a.b.stats[(size_t)u * 24 + i] = est[i];
+        }
+#endif
         if (a.b.in_used) a.b.in_used[u] = n;
         if (a.check_out) a.check_out[u] = check;
     }
