@@ -1776,20 +1776,27 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                         const uint32_t mbi = wave_incl_scan(ml), mbx = mbi - ml;
                         const uint32_t srcend = mstart - off + (ml < off ? ml : off);
                         uint64_t mm = __ballot(ml != 0);
-                        while (mm) {
+                        // A step's plan -- which matches go together, the owner of each of its bytes scattered into LDS -- depends on
+                        // positions only, never on data: the plan of the next step is laid out in LDS while this step's loads are in
+                        // flight (its LDS arrays are free again once this step's addresses are in registers).
+                        uint64_t inc = 0;
+                        uint32_t nbytes = 0, pk0 = 0;
+                        bool longm = false;
+                        auto plan = [&]() {  // the step that starts at mm's first match
                             ZC(10, 1);
                             const uint32_t k0 = (uint32_t)__ffsll((long long)mm) - 1;
                             const uint32_t d0 = rdlane(mstart, k0), b0 = rdlane(mbx, k0), l0 = rdlane(ml, k0);
-                            if (l0 > 256) {
-                                wave_match_copy(gout + d0, rdlane(off, k0), l0);
-                                mm &= mm - 1;
-                                continue;
+                            pk0 = k0;
+                            longm = l0 > 256;
+                            if (longm) {  // a long match is copied on its own, in its turn
+                                inc = 1ull << k0;
+                                return;
                             }
                             const uint64_t okm = __ballot(ml && (mbi - b0 <= 256u) && (lane == k0 || srcend <= d0));
                             const uint64_t rem = mm & ~okm;
-                            const uint64_t inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
+                            inc = rem ? (mm & ((1ull << ((uint32_t)__ffsll((long long)rem) - 1)) - 1ull)) : mm;
                             const uint32_t lastl = 63u - (uint32_t)__clzll((long long)inc);
-                            const uint32_t nbytes = rdlane(mbi, lastl) - b0;
+                            nbytes = rdlane(mbi, lastl) - b0;
                             L.xheads[lane] = 0;
                             LSYNC();
                             if ((inc >> lane) & 1ull) {
@@ -1799,6 +1806,15 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                                 L.xpar[3 * rank] = mstart;
                                 L.xpar[3 * rank + 1] = off;
                                 L.xpar[3 * rank + 2] = (ml - 1u) | (rel << 8);
+                            }
+                        };
+                        if (mm) plan();
+                        while (mm) {
+                            if (longm) {
+                                wave_match_copy(gout + rdlane(mstart, pk0), rdlane(off, pk0), rdlane(ml, pk0));
+                                mm &= ~inc;
+                                if (mm) plan();
+                                continue;
                             }
                             LSYNC();
                             const uint32_t h = L.xheads[lane];
@@ -1827,14 +1843,16 @@ __global__ __launch_bounds__(64, CHIP_ZSTD_WAVES) void zstd_kernel(BatchArgs a, 
                             uint8_t bytes[4];
 #pragma unroll
                             for (int j = 0; j < 4; j++) bytes[j] = gout[has[j] ? srcs[j] : 0u];
+                            LSYNC();  // (this step's reads of the plan are done: the arrays are free)
+                            mm &= ~inc;
+                            if (mm) plan();  // the next step's plan goes into LDS while the loads fly
                             uint32_t packed = (uint32_t)bytes[0] | ((uint32_t)bytes[1] << 8) | ((uint32_t)bytes[2] << 16) | ((uint32_t)bytes[3] << 24);
                             asm volatile("" : "+v"(packed));  // (keeps the compiler from storing the loaded bytes one by one after all)
 #pragma unroll
                             for (int j = 0; j < 4; j++)
                                 if (has[j]) gout[dsts[j]] = (uint8_t)(packed >> (8 * j));
-                            LSYNC();
-                            mm &= ~inc;
                         }
+                        LSYNC();
                     }
 #endif
                     ZT_END(6, zt6);
