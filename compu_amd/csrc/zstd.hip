@@ -344,6 +344,8 @@ __device__ bool huf_decode4(ZLds &L, const Bits &b, HufStream hs, uint8_t *gout,
         }
         if (scr && trip && trip <= HSCR_TRIPS) scr[(trip - 1u) * 64u + lane] = pend;
         const bool from_rows = scr && trip <= HSCR_TRIPS;
+        ZC(18, from_rows ? 0 : 1);
+        ZC(19, 1);
         WSYNC();
         // ---- the true chain of every stream: lane 0 of the group, then whatever it joined, ...
         const uint32_t nxt = reason == H_JOIN ? jl : 64u;

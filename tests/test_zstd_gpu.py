@@ -441,3 +441,37 @@ def test_an_offset_beyond_the_window_is_corruption_batch_and_stream(gpu):
                 assert err is None and got == len(want) and crc == zlib.crc32(want), (off, piece, err, got)
             else:
                 assert err == -20, (off, piece, err, got)
+
+
+def test_literal_paths_rows_and_second_decode(gpu):
+    """The literal decoder keeps the walk's symbols in scratch rows inside the frame's own output range and copies the owned pieces
+    out of them; it decodes a second time instead when the range has no room for the rows (small frames, tight capacities) or when a
+    round has lanes that walk more than 32 trips (codes of one or two bits: up to 256 symbols in a 256-bit segment).  Frames that take
+    each way -- skewed alphabets with a one-bit code, flat ones, sizes around the rows' 8.7 KB, capacity exactly the content size --
+    against the oracle."""
+    z = zstd_ref.load()
+    assert z is not None
+    rnd = random.Random(21)
+    datas, parts = [], []
+    for it in range(60):
+        n = rnd.choice([3000, 9000, 12000, 40000, 65536, 131072, 200000])
+        kind = it % 4
+        if kind == 0:    # one dominant byte: a one-bit code, more than 128 symbols per lane and round
+            data = bytes(97 if rnd.random() < 0.88 else rnd.randrange(256) for _ in range(n))
+        elif kind == 1:  # two dominant bytes: two-bit codes
+            data = bytes(rnd.choice(b"ab") if rnd.random() < 0.9 else rnd.randrange(256) for _ in range(n))
+        elif kind == 2:  # flat over 64 symbols: six-bit codes, the rows' usual case
+            data = bytes(32 + rnd.randrange(64) for _ in range(n))
+        else:            # a mix of both in one frame (several blocks when n > 128 KiB)
+            half = n // 2
+            data = bytes(97 if rnd.random() < 0.9 else rnd.randrange(256) for _ in range(half)) + bytes(32 + rnd.randrange(64) for _ in range(n - half))
+        comp = zstd_ref.compress(z, data, rnd.choice([1, 3]), True, rnd.random() < 0.7)
+        datas.append(data)
+        parts.append(comp)
+    caps = [len(d) + (0 if i % 2 else 4096) for i, d in enumerate(datas)]
+    outs, ol, iu, st = run_batch(gpu, FMT_ZSTD, parts, caps, check_tail=False)
+    ref = oracle_zstd_batch(parts, caps)
+    for i in range(len(parts)):
+        assert st[i] == 2 == ref[i][2], (i, st[i], ref[i][2])
+        assert outs[i] == datas[i] == ref[i][0], i
+        assert iu[i] == ref[i][1], (i, iu[i], ref[i][1])

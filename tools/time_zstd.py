@@ -52,7 +52,8 @@ if zstats is not None:
              6: "cycles: execution phase B (matches)", 7: "cycles: XXH64", 8: "trips: chunks of 64 sequences (chain runs)", 9: "trips: phase A steps",
              10: "trips: phase B steps", 11: "trips: literal rounds", 12: "trips: literal walk steps",
              13: "cycles: Huffman table (weights, their FSE table, code table)", 14: "cycles: the three sequence tables (descriptions, builds, re-coding)",
-             15: "cycles:   Huffman: description and FSE table of the weights", 16: "cycles:   Huffman: the weights' two-state decode", 17: "cycles:   Huffman: code table from the weights"}
+             15: "cycles:   Huffman: description and FSE table of the weights", 16: "cycles:   Huffman: the weights' two-state decode", 17: "cycles:   Huffman: code table from the weights",
+             18: "trips: literal rounds decoded a second time (no room for the rows, or more than 32 trips)", 19: "trips: literal rounds (again)"}
     for i in sorted(names):
         print(f"  {names[i]:85s} {z[i]:12.1f}" + (f"  ({100 * z[i] / z[0]:5.1f} %)" if i and (i < 8 or i >= 13) and z[0] else ""))
     print(f"  {'cycles: parallel part + offsets + placement (4 - 3 - 5 - 6)':85s} {z[4] - z[3] - z[5] - z[6]:12.1f}  ({100 * (z[4] - z[3] - z[5] - z[6]) / z[0]:5.1f} %)")
