@@ -37,7 +37,7 @@ struct alignas(16) ELds {
     uint32_t obuf[OBUF];
     uint32_t lentab[256];  // per match length 3..258: fixed-Huffman code with the extra bits | bit count << 16
 };
-static_assert(sizeof(ELds) <= 10240, "sixteen waves per CU (LDS is granted in 1280-byte steps)");
+static_assert(sizeof(ELds) <= 10240, "sixteen waves per CU");
 
 // 4 input bytes at byte offset `off` of the dword-aligned view (little endian)
 __device__ __forceinline__ uint32_t ld32(const uint32_t *g32, uint32_t total_dw, uint32_t off)
@@ -195,7 +195,7 @@ struct alignas(16) DLdsT {
 };
 using DLds = DLdsT<1>;
 using DLds2 = DLdsT<2>;
-static_assert(sizeof(DLds) <= 19200, "eight waves per CU (LDS is granted in 1280-byte steps)");
+static_assert(sizeof(DLds) <= 19200, "eight waves per CU");
 static_assert(sizeof(DLds2) <= 26880, "six waves per CU");
 
 // Code lengths of freq[0..n) (n <= 288) limited to maxbits into len[0..n): Huffman over (frequency, symbol)-sorted

@@ -188,7 +188,7 @@ constexpr uint32_t FLUSH_BYTES = 4 * (IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING + 1
 constexpr uint32_t HDR_BYTES = 4 * HDR_IN_DW + 4 * (1 << CL_ROOT) + 80 + sizeof(HuffMeta) + 64 + 320 + 2 * 288 + 2 * 32 + 2 * sizeof(HuffMeta);
 constexpr uint32_t PHASE_BYTES = 8 * WIN_DW > FLUSH_BYTES ? (8 * WIN_DW > HDR_BYTES ? 8 * WIN_DW : HDR_BYTES) : (FLUSH_BYTES > HDR_BYTES ? FLUSH_BYTES : HDR_BYTES);
 #ifndef CHIP_LDS_BYTES
-#define CHIP_LDS_BYTES 10240  // per wave; LDS is granted in 1280-byte steps: 10240 = 16 waves per CU, 8960 = 18, 7680 = 20
+#define CHIP_LDS_BYTES 10240  // per wave: 16 waves per CU; the occupancy query gives 18 at 8960 B and 20 at 8192 B (round 4, CHIP_DEBUG_GRID)
 #endif
 constexpr uint32_t POOL_WORDS = (CHIP_LDS_BYTES - 2 * 512 - 2 * 256 - PHASE_BYTES) / 4;
 constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;

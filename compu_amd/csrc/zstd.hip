@@ -69,7 +69,7 @@ struct alignas(16) ZLds {
     // baseline is the code itself, plus 3 for match lengths): read once per sequence
     uint32_t lltab[20], mltab[21];
 };
-static_assert(sizeof(ZLds) <= 11520, "fourteen waves per CU (LDS is granted in 1280-byte steps)");
+static_assert(sizeof(ZLds) <= 11520, "fourteen waves per CU would fit the LDS (the registers allow twelve)");
 
 // Streaming decoder only (BatchArgs::resume, one unit): checkpoint written after every completed block -- ZRES_HDR header words
 // ([0] 1 + input bytes consumed (0 = none), [1] output bytes in the buffer, [2..4] repeat offsets, [5] flags: 1 checksum, 2 content
