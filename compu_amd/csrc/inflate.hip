@@ -6,20 +6,20 @@
 // wrappers with Adler-32 / CRC-32 verification (RFC 1950 / 1952).
 //
 // Data flow per wave (inflate_kernel, the one-kernel path):  block header --> canonical-Huffman tables in LDS (two-level, see below)
-//   --> per block a sequence of SUPER-ROUNDS.  A super-round stages the next 64 x 384 bits of input in LDS (coalesced dword loads)
-//   from the true token boundary B on; lane i decodes the token chain that starts at B + 384 i (a guess, except for lane 0), marks
-//   the token boundaries it passes inside its own 384-bit segment in a bit map of the staged input, and keeps going past the
+//   --> per block a sequence of SUPER-ROUNDS.  A super-round stages the next 64 x 320 bits of input in LDS (coalesced dword loads)
+//   from the true token boundary B on; lane i decodes the token chain that starts at B + 320 i (a guess, except for lane 0), marks
+//   the token boundaries it passes inside its own 320-bit segment in a bit map of the staged input, and keeps going past the
 //   segment's end until it steps on a boundary marked by the owner of the segment it is in (from there on the two chains are the
 //   same), at most 1536 bits further (3072 in fixed-Huffman blocks).  Tokens (literal | length, distance) go to the lane's row of
 //   the wave's scratch in HBM / L2, 16 bytes per four tokens.  The chain of joins from lane 0 is the true token stream; it is found
-//   in registers (pointer doubling with ds_bpermute) and executed a chunk (<= 3.5 KB of output) at a time: 64 tokens per step
+//   in registers (pointer doubling with ds_bpermute) and executed a chunk (<= 2.5 KB of output) at a time: 64 tokens per step
 //   fetched through an LDS-DMA ring, output offsets by wave prefix sum, literals and queued matches assembled in LDS and stored
 //   coalesced into the unit's output range in HBM (the LZ77 window is the output itself).
 // The grid is persistent: waves take units from a counter, so the token scratch is one slot per resident wave.
 //
 // tokens_kernel is the same decoder with the execution left out: it appends a unit's true tokens to an arena in stream order and
 // leaves a record; lz77_kernel (lz77.hip) executes them in an LDS image of the unit's output.  This two-kernel pipeline is behind
-// CHIP_INFLATE_PIPE=1 (built, parity-green, measured slower than the one-kernel path in round 4).
+// CHIP_INFLATE_PIPE=1 ("Round 4": built, parity-green, measured slower than the one-kernel path).
 #include <cstddef>
 #include <cstdio>
 #include <cstdlib>
@@ -126,8 +126,10 @@ __device__ __forceinline__ uint32_t make_dist16(uint32_t sym, uint32_t len)
 // past its segment until it steps on a boundary marked by the owner of the segment it is in (from there on the two chains are
 // the same), at most XT_BITS further.  Every lane records up to ROW_TOKENS tokens.  S_BITS is an odd number of dwords so that
 // the 64 lanes' first window reads hit distinct LDS banks.
-#ifndef CHIP_S_BITS  // geometry overridable for experiments
-#define CHIP_S_BITS 384
+#ifndef CHIP_S_BITS  // geometry overridable for experiments (round 4: 320-bit segments and 2.5 KB chunks let 18 waves per CU in, 8960 B of LDS
+                     // each; at the full 65 536-unit launch that is 14.6 ms against 15.1 for 384 bits / 3.5 KB at 16 waves, 15.6 for this geometry at 16,
+                     // 15.5 at 17 waves with 352 bits, 15.3 at 19 with 288, 15.9 at 20 with 224 -- DESIGN.md sec. 8)
+#define CHIP_S_BITS 320
 #define CHIP_XT_BITS 1536
 #define CHIP_XT_BITS_FIXED 3072  // fixed-Huffman codes (nearly all 8 or 9 bits) fall into step slowly
 #define CHIP_ROW_TOKENS 256
@@ -172,7 +174,7 @@ struct HuffMeta {
 
 // LZ77 execution state of a chunk (see below)
 #ifndef CHIP_CHUNK_BYTES
-#define CHIP_CHUNK_BYTES 3584
+#define CHIP_CHUNK_BYTES 2560
 #endif
 #ifndef CHIP_COPY_LANE_MAX
 #define CHIP_COPY_LANE_MAX 32
@@ -188,7 +190,7 @@ constexpr uint32_t FLUSH_BYTES = 4 * (IMG_WORDS + 2 * MQ_CAP + 64 * TOK_RING + 1
 constexpr uint32_t HDR_BYTES = 4 * HDR_IN_DW + 4 * (1 << CL_ROOT) + 80 + sizeof(HuffMeta) + 64 + 320 + 2 * 288 + 2 * 32 + 2 * sizeof(HuffMeta);
 constexpr uint32_t PHASE_BYTES = 8 * WIN_DW > FLUSH_BYTES ? (8 * WIN_DW > HDR_BYTES ? 8 * WIN_DW : HDR_BYTES) : (FLUSH_BYTES > HDR_BYTES ? FLUSH_BYTES : HDR_BYTES);
 #ifndef CHIP_LDS_BYTES
-#define CHIP_LDS_BYTES 10240  // per wave: 16 waves per CU; the occupancy query gives 18 at 8960 B and 20 at 8192 B (round 4, CHIP_DEBUG_GRID)
+#define CHIP_LDS_BYTES 8960  // per wave: 18 waves per CU (the occupancy query: 16 at 10240 B, 17 at 9600, 19 at 8448, 20 at 8192; CHIP_DEBUG_GRID prints it)
 #endif
 constexpr uint32_t POOL_WORDS = (CHIP_LDS_BYTES - 2 * 512 - 2 * 256 - PHASE_BYTES) / 4;
 constexpr uint32_t POOL_U16 = 2 * POOL_WORDS;
@@ -1421,7 +1423,7 @@ __device__ CHIP_PHASE_FN void decode_block(WaveLds &L, InWin &w, uint32_t &pos, 
 }
 
 #ifndef CHIP_WAVES_PER_SIMD
-#define CHIP_WAVES_PER_SIMD 4
+#define CHIP_WAVES_PER_SIMD 5  // (18 waves per CU: two SIMDs hold five; 96 lane registers)
 #endif
 // one unit, start to finish, by the calling wave; scratch = the wave's token rows in HBM
 // PIPE (tokens kernel): nothing is executed and no result is written -- the unit's tokens and stored runs go to its record (E); a
