@@ -2033,7 +2033,13 @@ hipError_t launch_inflate_locked(const BatchArgs &a, hipStream_t stream)
     LaunchSlot sl;
     hipError_t e = slot_for(stream, a.n, sl);
     if (e != hipSuccess) return e;
-    const uint32_t blocks = a.n < (uint32_t)sl.blocks ? a.n : (uint32_t)sl.blocks;
+    uint32_t blocks = a.n < (uint32_t)sl.blocks ? a.n : (uint32_t)sl.blocks;
+#ifdef CHIP_EXP_EVEN_GRID  // probe: as many waves as give every wave the same number of units (no ragged last round)
+    if (blocks) {
+        const uint32_t per_wave = (a.n + blocks - 1) / blocks;
+        blocks = (a.n + per_wave - 1) / per_wave;
+    }
+#endif
     // A batch (not a streaming decoder's call, which carries its state in a.resume) takes the two-kernel pipeline: tokens_kernel,
     // lz77_kernel, then inflate_kernel over the units those two have put on the fallback list (usually none).
     if (!a.resume && pipe_enabled()) {
