@@ -1,4 +1,7 @@
-"""Timing-only run of a (possibly deliberately broken, experiment) build: COMPU_HIP_LIB=... python tools/time_run.py [kind] [units]"""
+"""Timing-only run of a (possibly deliberately broken, experiment) build: COMPU_HIP_LIB=... python tools/time_run.py [kind] [units]
+CAUTION (round 4): the default 16 384 units are exactly four units per wave of a 16-waves-per-CU persistent grid; a variant that changes the
+number of resident waves must be compared at the full launch size (tools/exp/w18_full.sh: bench.py --workload W at 65 536 units), or it
+is judged by its ragged last round."""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
